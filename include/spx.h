@@ -1,0 +1,176 @@
+/*
+ * spx.h — C ABI of libspx.so: the MI355X (gfx950) sparse-3D-convolution kernel library.
+ *
+ * This is the drop-in boundary "B3" of SURVEY.md §8(b).  The reference repository
+ * (blindopen/TSM-Det-Pointcloud-, an OpenPCDet 0.5.2 fork) reaches all of this arithmetic through
+ * the third-party `spconv.pytorch` / `spconv.utils` / `cumm.tensorview` Python packages
+ * (pinned spconv_cu118==2.3.8, cumm_cu118==0.7.11, reference `requirements.txt:1,21`), which are
+ * not vendored; every entry point below therefore cites the reference CALL SITE it serves.
+ *
+ * Conventions (all entry points):
+ *   - plain C, `extern "C"`, no torch / C++ types in any signature;
+ *   - every pointer named d_* or documented "device" is a device (HBM) pointer owned by the caller;
+ *     the library never allocates, frees, or synchronises: all scratch comes in through (ws, ws_bytes),
+ *     sized by the matching *_ws_bytes() query;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every kernel is enqueued on
+ *     it and the call returns immediately (graph-capture safe);
+ *   - data-dependent counts (number of voxels, number of active outputs) are RETURNED THROUGH DEVICE
+ *     POINTERS and may be CONSUMED through device pointers (`d_n*` arguments, nullable): when a `d_n`
+ *     argument is non-NULL the kernels read the live row count from it (it must be <= the host-side
+ *     capacity `n` that sizes the launch); when NULL the host value `n` is exact.  This lets a caller
+ *     chain voxelise -> rulebooks -> convolutions with no host synchronisation in between;
+ *   - return value: 0 (SPX_OK) or a negative SPX_ERR_* code; never throws, never exits;
+ *   - re-entrant; no global mutable state; one HIP context per process;
+ *   - row indices are int32, linear voxel keys are 64-bit, features are fp32 row-major [rows, channels];
+ *   - voxel indices are int32 [rows,4] = (batch, z, y, x), spatial shapes are (D,H,W) = (z,y,x) extents.
+ */
+#ifndef SPX_H_
+#define SPX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPX_ABI_VERSION 1
+
+#define SPX_OK 0
+#define SPX_ERR_INVALID_ARG (-1)  /* null pointer, non-positive extent, kernel volume > SPX_MAX_KVOL ... */
+#define SPX_ERR_WORKSPACE (-2)    /* ws == NULL or ws_bytes smaller than the *_ws_bytes() answer          */
+#define SPX_ERR_UNSUPPORTED (-3)  /* channel count / mode this build has no kernel for                     */
+#define SPX_ERR_LAUNCH (-4)       /* hipGetLastError() != hipSuccess after a launch                        */
+#define SPX_ERR_TOO_LARGE (-5)    /* rows >= 2^31 or grid cells >= 2^40                                    */
+
+#define SPX_MAX_KVOL 32 /* largest kernel volume kz*ky*kx supported (27 = 3x3x3 is the reference's max) */
+
+typedef void *spx_stream_t;
+
+/* Human-readable text for an SPX_ERR_* code (static storage). */
+const char *spx_strerror(int code);
+/* Returns SPX_ABI_VERSION of the loaded library. */
+int spx_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. Hard voxelisation (+ fused MeanVFE)
+ *    replaces: spconv.utils.Point2VoxelCPU3d(...).point_to_voxel(tv.from_numpy(points))
+ *      reference call site pcdet/datasets/processor/data_processor.py:37-43,55 (VoxelGeneratorWrapper),
+ *      driven by DataProcessor.transform_points_to_voxels, data_processor.py:127-155, and the batch
+ *      concatenation of DatasetTemplate.collate_batch, pcdet/datasets/dataset.py:161-229;
+ *    and (mean != NULL) MeanVFE.forward, pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31.
+ *
+ *    Semantics: for each point in input order, c_j = floor((p_j-lo_j)/vsize_j)
+ *    in fp32 with a true division; the point is dropped if any c_j is outside [0, grid_j).  Voxels are
+ *    numbered in first-occurrence order per frame; a new voxel is created only while the frame has
+ *    fewer than max_voxels; a point is appended to its voxel only while the voxel holds fewer than
+ *    max_points points.  Frames are processed independently and emitted batch-major.
+ *
+ *    points     device [n_points, point_stride] fp32.  xyz = columns xyz_col..xyz_col+2; the `c`
+ *               features copied to the voxel are columns feat_col..feat_col+c-1.
+ *    batch_col  column holding the frame index as a float (collate_batch's leading column), or -1
+ *               for a single frame.  Points of one frame must be contiguous, frames ascending.
+ *    range      host float[6] = (x0,y0,z0,x1,y1,z1); vsize host float[3] = (vx,vy,vz);
+ *    grid       host int32[3] = (gx,gy,gz) = round((hi-lo)/vsize), data_processor.py:129-130.
+ *    voxels     device [cap, max_points, c] fp32, zero padded (may be NULL when only `mean` is wanted)
+ *    coords     device [cap, 4] int32 (b,z,y,x)
+ *    num_points device [cap] int32
+ *    mean       device [cap, c] fp32 = sum over kept points / max(num,1)  (NULL to skip)
+ *    d_num_voxels device int64[1]: total voxels M written (rows [0,M) of every output are valid)
+ *    cap        rows available in the outputs; must be >= min(n_points, batch*max_voxels)
+ * ---------------------------------------------------------------------------------------------- */
+size_t spx_voxelize_ws_bytes(int64_t n_points, int batch, int max_points);
+int spx_voxelize(const float *points, int64_t n_points, int point_stride, int xyz_col, int feat_col, int c,
+                 int batch_col, int batch, const float *range, const float *vsize, const int32_t *grid,
+                 int max_points, int max_voxels, float *voxels, int32_t *coords, int32_t *num_points,
+                 float *mean, int64_t *d_num_voxels, int64_t cap, void *ws, size_t ws_bytes,
+                 spx_stream_t stream);
+
+/* Stand-alone MeanVFE for voxels produced elsewhere (e.g. by CPU dataloader workers):
+ * out[v,:] = sum_t voxels[v,t,:] / max(num[v],1); replaces mean_vfe.py:26-29. */
+int spx_mean_vfe(const float *voxels, const int32_t *num_points, int64_t n, const int64_t *d_n, int max_points,
+                 int c, float *out, spx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. Submanifold rulebook (hash insert + kernel-offset probe)
+ *    replaces: the indice-pair build inside spconv.pytorch.SubMConv3d.forward, reference call sites
+ *      pcdet/models/backbones_3d/spconv_backbone.py:86,93,99-100,106-107,113-114 (indice_key subm1..4).
+ *    pair[k*pair_ld + o] = row of the active voxel at coord(o) + (k - ksize/2)*dil in the same batch
+ *    element, or -1;  k = (kz*KH + ky)*KW + kx.   Output rows == input rows (same order).
+ *    The backward (dgrad) table of a submanifold conv is the same table read at K-1-k.
+ *    cnt    device int32[K]: number of valid pairs per offset (may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+size_t spx_subm_rulebook_ws_bytes(int64_t n);
+int spx_subm_rulebook(const int32_t *idx, int64_t n, const int64_t *d_n, int batch, const int32_t *shape,
+                      const int32_t *ksize, const int32_t *dil, int32_t *pair, int64_t pair_ld, int32_t *cnt,
+                      void *ws, size_t ws_bytes, spx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3. Regular (strided) sparse-convolution rulebook
+ *    replaces: the indice-pair build inside spconv.pytorch.SparseConv3d.forward, reference call sites
+ *      spconv_backbone.py:98,105,112 (k3 s2, keys spconv2..4) and :121-122 (k(3,1,1) s(2,1,1), spconv_down2).
+ *    Candidate outputs o = (i + pad - k*dil)/stride where divisible and 0 <= o < out_shape;
+ *    out_idx = unique candidates in ASCENDING linear key ((b*D+z)*H+y)*W+x (canonical order).
+ *      out_shape  host int32[3] = floor((in + 2*pad - dil*(k-1) - 1)/stride) + 1  (caller computes; checked)
+ *      out_idx    device [cap,4] int32
+ *      pair_fwd   device [K, cap]  int32 : pair_fwd[k*cap + o] = input row feeding output o at offset k, or -1
+ *      pair_bwd   device [K, n_in] int32 : pair_bwd[k*n_in + i] = output row fed by input i at offset k, or -1
+ *      cnt        device int32[K] (nullable);  d_n_out device int64[1] = number of active outputs
+ *      cap        output-row capacity, >= min(prod(ceil(k/s)) * n_in, batch*out cells)  (spx_conv_out_cap)
+ * ---------------------------------------------------------------------------------------------- */
+int64_t spx_conv_out_cap(int64_t n_in, int batch, const int32_t *out_shape, const int32_t *ksize,
+                         const int32_t *stride);
+size_t spx_conv_rulebook_ws_bytes(int64_t n_in, int batch, const int32_t *out_shape);
+int spx_conv_rulebook(const int32_t *idx, int64_t n_in, const int64_t *d_n_in, int batch, const int32_t *in_shape,
+                      const int32_t *out_shape, const int32_t *ksize, const int32_t *stride, const int32_t *pad,
+                      const int32_t *dil, int32_t *out_idx, int32_t *pair_fwd, int32_t *pair_bwd, int32_t *cnt,
+                      int64_t *d_n_out, int64_t cap, void *ws, size_t ws_bytes, spx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 4. Sparse convolution arithmetic
+ *    replaces: spconv.pytorch.{SubMConv3d,SparseConv3d}.forward and their autograd backward, the 12
+ *      call sites spconv_backbone.py:86,93,98-100,105-107,112-114,121; backward is triggered by
+ *      loss.backward() at tools/train_utils/train_utils.py:53.
+ *
+ *    Weights arrive in the reference parameter layout  w[Cout][K][Cin]  (= spconv 2.x
+ *    weight[Cout,kz,ky,kx,Cin], detector3d_template.py:547-562) and are re-laid for the MFMA operand
+ *    order by spx_pack_weight (mode 0: forward operand W_k[ci][co]; mode 1: dgrad operand W_k^T).
+ *    packed size = K*Cin*Cout floats in both modes.
+ *
+ *    forward : out[o,co] = sum_k sum_ci in[pair[k*ld+o], ci] * w[co][k][ci]          (pair = forward table)
+ *    dgrad   : din[i,ci] = sum_k sum_co dout[pairT[k*ld+i], co] * w[co][k][ci]       (pairT = backward table;
+ *              for a submanifold conv pass the forward table and flip_k = 1)
+ *      -> both are spx_conv_gemm: "rows of `src` gathered through `pair`, contracted with packed weights".
+ *    Optional fused epilogue:  y = acc*scale[c] + shift[c] (both nullable), then ReLU if relu != 0.
+ *    wgrad   : dw[co][k][ci] = sum_o dout[o,co] * in[pair[k*ld+o], ci]                (reference layout, fp32)
+ * ---------------------------------------------------------------------------------------------- */
+int spx_pack_weight(const float *w, int cout, int kvol, int cin, int mode, float *packed, spx_stream_t stream);
+
+int spx_conv_gemm(const float *src, int c_src, const float *w_packed, int c_dst, int kvol, int flip_k,
+                  const int32_t *pair, int64_t pair_ld, int64_t n_dst, const int64_t *d_n_dst,
+                  const float *scale, const float *shift, int relu, float *dst, spx_stream_t stream);
+
+size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n_out);
+int spx_conv_wgrad(const float *in, int cin, const float *dout, int cout, int kvol, const int32_t *pair,
+                   int64_t pair_ld, int64_t n_out, const int64_t *d_n_out, float *dw, void *ws, size_t ws_bytes,
+                   spx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 5. Densify (BEV collapse feed)
+ *    replaces: spconv.pytorch.SparseConvTensor.dense(), reference call site
+ *      pcdet/models/backbones_2d/map_to_bev/height_compression.py:21 (followed by the view at :22-23).
+ *    layout 0: dense[b][c][z][y][x]  (contiguous NCDHW, what .dense() returns)
+ *    layout 1: dense[b][y][x][c][z]  (the same logical [B,C,D,H,W] tensor stored so that
+ *              view(B, C*D, H, W) is channels_last: BEV channel c*D+z is the fastest axis)
+ *    The caller zero-fills `dense` (hipMemsetAsync) before spx_densify; spx_densify_bwd gathers
+ *    dfeat[row,c] = ddense[...] (autograd of .dense()).
+ * ---------------------------------------------------------------------------------------------- */
+int spx_densify(const float *feat, const int32_t *idx, int64_t n, const int64_t *d_n, int c, int batch,
+                const int32_t *shape, int layout, float *dense, spx_stream_t stream);
+int spx_densify_bwd(const float *ddense, const int32_t *idx, int64_t n, const int64_t *d_n, int c, int batch,
+                    const int32_t *shape, int layout, float *dfeat, spx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPX_H_ */

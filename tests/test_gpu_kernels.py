@@ -1,0 +1,337 @@
+"""HIP-vs-oracle parity for every kernel family, called through the C ABI (spx.ops -> libspx.so).
+
+Bars (BASELINE.json north_star): voxel indices / rulebooks BIT-EXACT; fp32 features within a stated
+tolerance: |err| <= 2e-5 * max(1, max|ref|) for a single conv (fp32 MFMA == k-ordered fmaf chain; the
+oracle sums in another order, so round-off differs by a few ulp per accumulated term).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 2e-5
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    err = float(np.abs(a - b).max()) if a.size else 0.0
+    assert err <= tol * scale, "max|err| %.3e > %.1e * %.3g" % (err, tol, scale)
+
+
+def _rulebook(ops, d_idx, batch, shape, k, s, p, subm):
+    if subm:
+        return ops.subm_rulebook(d_idx, batch, shape, k, want_cnt=True)
+    return ops.conv_rulebook(d_idx, batch, shape, k, s, p, want_cnt=True)
+
+
+# ------------------------------------------------------------------------------------------ golden fixtures
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "dense_conv_*.npz"))))
+def test_golden_dense_conv(path, orc):
+    """Committed dense-F.conv3d vectors: index set exact, values / dgrad / wgrad to fp32 round-off."""
+    from spx import ops
+    d = np.load(path)
+    dev = _dev()
+    idx = torch.from_numpy(d["idx"]).to(dev)
+    batch, shape = int(d["batch"]), [int(x) for x in d["shape"]]
+    k, s, p = [int(x) for x in d["k"]], [int(x) for x in d["s"]], [int(x) for x in d["p"]]
+    rb = _rulebook(ops, idx, batch, shape, k, s, p, bool(d["subm"]))
+    assert rb.n_out == d["out_idx"].shape[0]
+    assert np.array_equal(rb.out_indices.cpu().numpy(), d["out_idx"])
+    assert rb.out_shape == [int(x) for x in d["out_spatial"]]
+    w = torch.from_numpy(d["w"]).to(dev)
+    feat = torch.from_numpy(d["feat"]).to(dev)
+    cout, cin, K = w.shape[0], w.shape[-1], rb.kvol
+    out = ops.conv_gemm(feat, ops.pack_weight(w, 0), cout, K, rb.pair, rb.ld, rb.n_out)
+    _close(out.cpu().numpy(), d["out"])
+    dout = torch.from_numpy(d["dout"]).to(dev)
+    wt = ops.pack_weight(w, 1)
+    if rb.subm:
+        din = ops.conv_gemm(dout, wt, cin, K, rb.pair, rb.ld, rb.n_in, flip_k=True)
+    else:
+        din = ops.conv_gemm(dout, wt, cin, K, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in)
+    _close(din.cpu().numpy(), d["dfeat"])
+    dw = ops.conv_wgrad(feat, dout, rb.pair, rb.ld, rb.n_out, tuple(w.shape))
+    _close(dw.cpu().numpy(), d["dw"], tol=5e-5)
+
+
+# ------------------------------------------------------------------------------------------ rulebooks
+
+def _frame_indices(orc, cfg_id, nframes):
+    from pcdet_amd.datasets import synthetic as syn
+    geom = syn.CONFIGS[cfg_id]["geom"]
+    idx = []
+    for b in range(nframes):
+        f = syn.make_frame(cfg_id, b)
+        _v, c, _n = orc.voxelize(f["points"], geom["point_cloud_range"], geom["voxel_size"], 5, 400000)
+        idx.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+    shape = [int(x) for x in (syn.grid_size_of(geom)[::-1] + [1, 0, 0])]
+    return np.concatenate(idx, 0), shape
+
+
+BACKBONE_GEOMS = [
+    ("subm", (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ("sp", (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ("sp", (3, 3, 3), (2, 2, 2), (0, 1, 1)),
+    ("sp", (3, 1, 1), (2, 1, 1), (0, 0, 0)),
+]
+
+
+@pytest.mark.parametrize("cfg_id,nframes", [(1, 2), (2, 2)])
+def test_rulebooks_bit_exact_vs_oracle(cfg_id, nframes, orc):
+    """Every rulebook geometry of VoxelBackBone8x (spconv_backbone.py:86-122), chained through the four
+    levels, bit-exact against the oracle: out indices (canonical order), pair tables, per-offset counts."""
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, cfg_id, nframes)
+    dev = _dev()
+    for kind, k, s, p in BACKBONE_GEOMS:
+        d_idx = torch.from_numpy(idx_np).to(dev)
+        if kind == "subm":
+            rb = ops.subm_rulebook(d_idx, nframes, shape, k, want_cnt=True)
+            pair_o, cnt_o = orc.subm_rulebook(idx_np, shape, k)
+            assert np.array_equal(rb.pair[:, :rb.n_out].cpu().numpy(), pair_o)
+            assert np.array_equal(rb.cnt.cpu().numpy(), cnt_o)
+        else:
+            rb = ops.conv_rulebook(d_idx, nframes, shape, k, s, p, want_cnt=True)
+            oi, pf, pb, cnt_o, oshape = orc.conv_rulebook(idx_np, shape, k, s, p)
+            assert rb.n_out == oi.shape[0] and rb.out_shape == oshape
+            assert np.array_equal(rb.out_indices.cpu().numpy(), oi)
+            assert np.array_equal(rb.pair[:, :rb.n_out].cpu().numpy(), pf)
+            assert np.array_equal(rb.pair_bwd.cpu().numpy(), pb)
+            assert np.array_equal(rb.cnt.cpu().numpy(), cnt_o)
+            idx_np, shape = oi, oshape  # feed the next level
+
+
+def test_rulebook_edge_cases(orc):
+    from spx import ops
+    dev = _dev()
+    shape = [5, 6, 7]
+    # empty input
+    e = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    rb = ops.subm_rulebook(e, 1, shape, (3, 3, 3))
+    assert rb.n_out == 0
+    rb = ops.conv_rulebook(e, 1, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    assert rb.n_out == 0
+    # single voxel in a corner, and a fully dense tiny grid (every offset valid in the interior)
+    for idx_np in (np.array([[0, 0, 0, 0]], np.int32),
+                   np.array([[1, 4, 5, 6]], np.int32),
+                   np.stack(np.meshgrid([0, 1], range(5), range(6), range(7), indexing="ij"), -1).reshape(-1, 4)
+                   .astype(np.int32)):
+        d_idx = torch.from_numpy(idx_np).to(dev)
+        rb = ops.subm_rulebook(d_idx, 2, shape, (3, 3, 3), want_cnt=True)
+        pair_o, cnt_o = orc.subm_rulebook(idx_np, shape)
+        assert np.array_equal(rb.pair[:, :rb.n_out].cpu().numpy(), pair_o)
+        for k, s, p in (((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (1, 1, 1), (1, 1, 1)),
+                        ((2, 2, 2), (2, 2, 2), (0, 0, 0)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))):
+            rb = ops.conv_rulebook(d_idx, 2, shape, k, s, p, want_cnt=True)
+            oi, pf, pb, cnt_o, _ = orc.conv_rulebook(idx_np, shape, k, s, p)
+            assert np.array_equal(rb.out_indices.cpu().numpy(), oi)
+            assert np.array_equal(rb.pair[:, :rb.n_out].cpu().numpy(), pf)
+            assert np.array_equal(rb.pair_bwd.cpu().numpy(), pb)
+            assert np.array_equal(rb.cnt.cpu().numpy(), cnt_o)
+
+
+def test_rulebook_properties_full_size(orc):
+    """BASELINE cfg 3 size (Waymo, 2 x 80k voxels): size-independent properties, no oracle needed.
+    subm symmetry pair[k][o]=i <=> pair[K-1-k][i]=o; strided fwd/bwd tables are inverse maps; out keys
+    strictly ascending; every output has >= 1 pair; pair counts agree between tables."""
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, 3, 2)
+    dev = _dev()
+    d_idx = torch.from_numpy(idx_np).to(dev)
+    rb = ops.subm_rulebook(d_idx, 2, shape, (3, 3, 3), want_cnt=True)
+    pair = rb.pair[:, :rb.n_out]
+    K = rb.kvol
+    rows = torch.arange(rb.n_out, device=dev, dtype=torch.int32)
+    assert torch.equal(pair[K // 2], rows)
+    for k in range(K):
+        o = (pair[k] >= 0).nonzero()[:, 0]
+        i = pair[k][o].long()
+        assert torch.equal(pair[K - 1 - k][i], o.int())
+    rb2 = ops.conv_rulebook(d_idx, 2, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), want_cnt=True)
+    oi = rb2.out_indices.long()
+    key = ((oi[:, 0] * rb2.out_shape[0] + oi[:, 1]) * rb2.out_shape[1] + oi[:, 2]) * rb2.out_shape[2] + oi[:, 3]
+    assert bool((key[1:] > key[:-1]).all())
+    pf, pb = rb2.pair[:, :rb2.n_out], rb2.pair_bwd
+    assert bool(((pf >= 0).sum(0) >= 1).all())
+    assert int((pf >= 0).sum()) == int((pb >= 0).sum()) == int(rb2.cnt.sum())
+    for k in range(K):
+        i = (pb[k] >= 0).nonzero()[:, 0]
+        assert torch.equal(pf[k][pb[k][i].long()], i.int())
+
+
+# ------------------------------------------------------------------------------------------ arithmetic
+
+CHANNELS = [(4, 16), (5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (7, 9),
+            (48, 24)]
+
+
+@pytest.mark.parametrize("cin,cout", CHANNELS)
+def test_conv_fwd_dgrad_wgrad_vs_oracle(cin, cout, orc):
+    """Every channel pair of VoxelBackBone8x (+ MFMA-untiled ones) on KITTI-crop geometry, subm and strided."""
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, 1, 1)
+    dev = _dev()
+    d_idx = torch.from_numpy(idx_np).to(dev)
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    feat = torch.randn(idx_np.shape[0], cin, generator=g)
+    w = torch.randn(cout, 3, 3, 3, cin, generator=g) * (1.0 / np.sqrt(27 * cin))
+    for subm in (True, False):
+        rb = (ops.subm_rulebook(d_idx, 1, shape, (3, 3, 3)) if subm else
+              ops.conv_rulebook(d_idx, 1, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1)))
+        pair_np = rb.pair[:, :rb.n_out].cpu().numpy()
+        out = ops.conv_gemm(feat.to(dev), ops.pack_weight(w.to(dev), 0), cout, 27, rb.pair, rb.ld, rb.n_out)
+        ref = orc.conv_fwd(feat.numpy(), w.numpy(), pair_np, acc64=True)
+        _close(out.cpu().numpy(), ref)
+        # fused epilogue: scale/shift/relu
+        sc = torch.rand(cout, generator=g) + 0.5
+        sh = torch.randn(cout, generator=g)
+        out2 = ops.conv_gemm(feat.to(dev), ops.pack_weight(w.to(dev), 0), cout, 27, rb.pair, rb.ld, rb.n_out,
+                             scale=sc.to(dev), shift=sh.to(dev), relu=True)
+        _close(out2.cpu().numpy(), np.maximum(ref * sc.numpy() + sh.numpy(), 0))
+        dout = torch.randn(rb.n_out, cout, generator=g)
+        wt = ops.pack_weight(w.to(dev), 1)
+        if subm:
+            din = ops.conv_gemm(dout.to(dev), wt, cin, 27, rb.pair, rb.ld, rb.n_in, flip_k=True)
+        else:
+            din = ops.conv_gemm(dout.to(dev), wt, cin, 27, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in)
+        _close(din.cpu().numpy(), orc.conv_dgrad(dout.numpy(), w.numpy(), pair_np, rb.n_in))
+        dw = ops.conv_wgrad(feat.to(dev), dout.to(dev), rb.pair, rb.ld, rb.n_out, tuple(w.shape))
+        _close(dw.cpu().numpy(), orc.conv_wgrad(feat.numpy(), dout.numpy(), pair_np, tuple(w.shape)), tol=1e-4)
+
+
+def test_conv_full_size_linearity_and_oracle(orc):
+    """cfg 2 size (4 x 16k voxels, 64->64 subm3-like): linearity conv(a*x+y) = a*conv(x)+conv(y) and a
+    direct oracle comparison (numpy gather-GEMM-scatter)."""
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, 2, 4)
+    dev = _dev()
+    d_idx = torch.from_numpy(idx_np).to(dev)
+    rb = ops.subm_rulebook(d_idx, 4, shape, (3, 3, 3))
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(rb.n_in, 64, generator=g).to(dev)
+    y = torch.randn(rb.n_in, 64, generator=g).to(dev)
+    w = (torch.randn(64, 3, 3, 3, 64, generator=g) / np.sqrt(27 * 64)).to(dev)
+    wp = ops.pack_weight(w, 0)
+    fx = ops.conv_gemm(x, wp, 64, 27, rb.pair, rb.ld, rb.n_out)
+    fy = ops.conv_gemm(y, wp, 64, 27, rb.pair, rb.ld, rb.n_out)
+    fz = ops.conv_gemm(2.5 * x + y, wp, 64, 27, rb.pair, rb.ld, rb.n_out)
+    _close(fz.cpu().numpy(), (2.5 * fx + fy).cpu().numpy(), tol=5e-5)
+    ref = orc.conv_fwd_gemm(x.cpu().numpy(), w.cpu().numpy(), rb.pair[:, :rb.n_out].cpu().numpy())
+    _close(fx.cpu().numpy(), ref)
+    # determinism: bitwise identical on a second launch
+    assert torch.equal(fx, ops.conv_gemm(x, wp, 64, 27, rb.pair, rb.ld, rb.n_out))
+
+
+# ------------------------------------------------------------------------------------------ densify
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_densify_and_backward(channels_last, orc):
+    from spx import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    batch, shape, c = 3, [2, 20, 18], 128
+    cells = batch * shape[0] * shape[1] * shape[2]
+    lin = torch.randperm(cells, generator=g)[:500].sort()[0]
+    vol = shape[0] * shape[1] * shape[2]
+    idx = torch.stack([lin // vol, (lin % vol) // (shape[1] * shape[2]), (lin // shape[2]) % shape[1],
+                       lin % shape[2]], 1).int()
+    feat = torch.randn(500, c, generator=g)
+    dense = ops.densify(feat.to(dev), idx.to(dev), batch, shape, channels_last=channels_last)
+    assert list(dense.shape) == [batch, c, *shape]
+    ref = orc.densify(feat.numpy(), idx.numpy(), batch, shape)
+    assert np.array_equal(dense.cpu().numpy(), ref)
+    # height_compression.py:22-23: view(N, C*D, H, W) must be legal on what dense() returns
+    bev = dense.view(batch, c * shape[0], shape[1], shape[2])
+    assert np.array_equal(bev.cpu().numpy(), ref.reshape(batch, c * shape[0], shape[1], shape[2]))
+    if channels_last:
+        assert bev.is_contiguous(memory_format=torch.channels_last)
+    dd = torch.randn(batch, c, *shape, generator=g)
+    dfeat = ops.densify_bwd(dd.to(dev), idx.to(dev), batch, shape, channels_last=channels_last)
+    ii = idx.long()
+    assert torch.equal(dfeat.cpu(), dd[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]])
+
+
+# ------------------------------------------------------------------------------------------ voxelise
+
+def _vox_check(ops, orc, frames, geom_range, vsize, max_points, max_voxels):
+    """frames: list of [Np, C] arrays -> GPU batched voxelise vs per-frame oracle + concat (dataset.py:161-229)."""
+    dev = _dev()
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1)
+                          for b, f in enumerate(frames)], 0)
+    out = ops.voxelize(torch.from_numpy(pts).to(dev), geom_range, vsize, max_points, max_voxels,
+                       batch_size=len(frames), batch_col=0, xyz_col=1, feat_col=1)
+    vs, cs, ns = [], [], []
+    for b, f in enumerate(frames):
+        v, c, n = orc.voxelize(f, geom_range, vsize, max_points, max_voxels)
+        vs.append(v)
+        cs.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+        ns.append(n)
+    v, c, n = np.concatenate(vs), np.concatenate(cs), np.concatenate(ns)
+    assert out["num_voxels"] == v.shape[0]
+    assert np.array_equal(out["coords"].cpu().numpy(), c)
+    assert np.array_equal(out["num_points"].cpu().numpy(), n)
+    assert np.array_equal(out["voxels"].cpu().numpy(), v)
+    _close(out["mean"].cpu().numpy(), orc.mean_vfe(v, n), tol=1e-6)
+    return out
+
+
+def test_voxelize_synthetic_frames(orc):
+    from pcdet_amd.datasets import synthetic as syn
+    from spx import ops
+    g = syn.KITTI
+    frames = [syn.make_frame(1, i)["points"] for i in range(3)]
+    _vox_check(ops, orc, frames, g["point_cloud_range"], g["voxel_size"], 5, 16000)
+    # voxel budget smaller than the scene: first-occurrence voxels survive, later ones (and their points) drop
+    _vox_check(ops, orc, frames, g["point_cloud_range"], g["voxel_size"], 5, 3000)
+    _vox_check(ops, orc, frames, g["point_cloud_range"], g["voxel_size"], 2, 4999)
+    gw = syn.WAYMO
+    frames = [syn.make_frame(3, i)["points"] for i in range(2)]
+    _vox_check(ops, orc, frames, gw["point_cloud_range"], gw["voxel_size"], 5, 150000)
+
+
+def test_voxelize_known_answers(orc):
+    """Hand-built points hitting each rule: range edges (hi - 0.0002, common_utils.py:66-70), exact cell
+    boundaries, negative / out-of-range / NaN coordinates, > max_points in a voxel, empty frame."""
+    from spx import ops
+    rng = [0.0, -40.0, -3.0, 70.4, 40.0, 1.0]
+    vs = [0.05, 0.05, 0.1]
+    r = np.random.default_rng(5)
+    pts = [
+        [0.0, -40.0, -3.0, 0.1], [70.4 - 0.0002, 40.0 - 0.0002, 1.0 - 0.0002, 0.2], [70.4, 0.0, 0.0, 0.3],
+        [-1e-6, 0.0, 0.0, 0.4], [35.0, 40.0, 0.0, 0.5], [0.05, 0.05, 0.1, 0.6], [0.0499999, 0.0, 0.0, 0.7],
+        [np.nan, 0.0, 0.0, 0.8], [10.0, np.inf, 0.0, 0.9], [0.15, -39.95, -2.9, 1.0],
+    ]
+    crowd = np.concatenate([np.full((9, 1), 12.34), np.full((9, 1), 5.67), np.full((9, 1), -1.0),
+                            np.arange(9)[:, None] / 10.0], 1) + np.concatenate([r.random((9, 3)) * 0.01,
+                                                                               np.zeros((9, 1))], 1)
+    bounds = np.stack([np.arange(200) * 0.05, np.arange(200) * 0.05 - 5.0, np.arange(200) % 40 * 0.1 - 3.0,
+                       np.arange(200) / 200.0], 1)
+    f0 = np.concatenate([np.asarray(pts), crowd, bounds], 0).astype(np.float32)
+    f1 = np.zeros((0, 4), np.float32)           # empty frame in the middle of a batch
+    f2 = f0[::-1].copy()                        # same points, reversed order -> different voxel numbering
+    out = _vox_check(ops, orc, [f0, f1, f2], rng, vs, 5, 16000)
+    assert int(out["num_points"].max()) == 5
+    _vox_check(ops, orc, [f0, f1, f2], rng, vs, 3, 50)
+    _vox_check(ops, orc, [f1], rng, vs, 5, 10)
+
+
+def test_mean_vfe_standalone(orc):
+    from spx import ops
+    g = torch.Generator().manual_seed(11)
+    num = torch.randint(0, 6, (1000,), generator=g).int()
+    vox = torch.randn(1000, 5, 4, generator=g) * (torch.arange(5)[None, :, None] < num[:, None, None])
+    out = ops.mean_vfe(vox.to(_dev()), num.to(_dev()))
+    _close(out.cpu().numpy(), orc.mean_vfe(vox.numpy(), num.numpy()), tol=1e-6)

@@ -1,0 +1,90 @@
+"""CPU suite: the oracle against the committed golden vectors (tests/golden/*.npz).
+
+dense_conv_*.npz were produced by tests/golden/make_golden_dense.py from PyTorch DENSE ops only
+(F.conv3d + autograd), so they pin the oracle's rulebooks (index sets, canonical order) and conv arithmetic
+independently of both the oracle and the HIP library.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "dense_conv_*.npz")))
+
+
+def test_fixtures_present():
+    assert len(FIXTURES) >= 5
+
+
+@pytest.mark.parametrize("path", FIXTURES)
+def test_oracle_matches_dense_conv3d(path, orc):
+    d = np.load(path)
+    if d["subm"]:
+        pair, cnt = orc.subm_rulebook(d["idx"], d["shape"], d["k"])
+        out_idx, pb = d["idx"], None
+    else:
+        out_idx, pair, pb, cnt, oshape = orc.conv_rulebook(d["idx"], d["shape"], d["k"], d["s"], d["p"])
+        assert list(oshape) == [int(x) for x in d["out_spatial"]]
+    assert np.array_equal(out_idx, d["out_idx"])          # integer, exact, in nonzero() (= canonical) order
+    assert int(cnt.sum()) == int((pair >= 0).sum())
+    for conv in (orc.conv_fwd, orc.conv_fwd_gemm):
+        assert np.abs(conv(d["feat"], d["w"], pair) - d["out"]).max() < 2e-6
+    assert np.abs(orc.conv_dgrad(d["dout"], d["w"], pair, d["idx"].shape[0]) - d["dfeat"]).max() < 5e-6
+    assert np.abs(orc.conv_wgrad(d["feat"], d["dout"], pair, d["w"].shape) - d["dw"]).max() < 2e-5
+    if pb is not None:  # forward and backward tables are inverse maps
+        for k in range(pair.shape[0]):
+            o = np.nonzero(pair[k] >= 0)[0]
+            assert np.array_equal(pb[k][pair[k, o]], o)
+
+
+def test_oracle_densify_bev_channel_order(orc):
+    """height_compression.py:21-23: dense() then view(N, C*D, H, W)  =>  BEV channel = c*D + z."""
+    rng = np.random.default_rng(0)
+    idx = np.array([[0, 0, 1, 2], [0, 1, 1, 2], [1, 1, 0, 0]], np.int32)
+    feat = rng.standard_normal((3, 4)).astype(np.float32)
+    dense = orc.densify(feat, idx, 2, [2, 3, 4])
+    bev = dense.reshape(2, 8, 3, 4)
+    for r, (b, z, y, x) in enumerate(idx):
+        for c in range(4):
+            assert bev[b, c * 2 + z, y, x] == feat[r, c]
+    assert np.count_nonzero(dense) == 12
+
+
+def test_oracle_voxelize_rules(orc):
+    """Sequential semantics of SURVEY.md §8a row a1 on a hand-checkable case."""
+    rng_ = [0.0, 0.0, 0.0, 4.0, 4.0, 2.0]
+    vs = [1.0, 1.0, 1.0]
+    pts = np.array([[0.5, 0.5, 0.5, 1], [3.5, 0.5, 0.5, 2], [0.6, 0.4, 0.2, 3], [4.0, 0.0, 0.0, 4],
+                    [-0.1, 0.0, 0.0, 5], [0.1, 0.9, 0.9, 6], [2.5, 2.5, 1.5, 7], [0.2, 0.2, 0.2, 8]], np.float32)
+    v, c, n = orc.voxelize(pts, rng_, vs, 3, 10)
+    assert c.tolist() == [[0, 0, 0], [0, 0, 3], [1, 2, 2]]      # (z,y,x), first-occurrence order
+    assert n.tolist() == [3, 1, 1]                              # 4th point of voxel 0 dropped (max_points=3)
+    assert v[0, :, 3].tolist() == [1, 3, 6] and v[1, 0, 3] == 2 and v[2, 0, 3] == 7
+    assert np.all(v[1, 1:] == 0)
+    v, c, n = orc.voxelize(pts, rng_, vs, 3, 2)                 # voxel budget 2: third voxel never created
+    assert c.tolist() == [[0, 0, 0], [0, 0, 3]] and n.tolist() == [3, 1]
+    m = orc.mean_vfe(v, n)
+    assert np.allclose(m[0, 3], (1 + 3 + 6) / 3.0)
+
+
+def test_oracle_backbone8x_shapes(orc):
+    """VoxelBackBone8x wiring (spconv_backbone.py:85-125): stage shapes 41x1600x1408 -> 2x200x176."""
+    from pcdet_amd.datasets import synthetic as syn
+    f = syn.make_frame(1, 0)
+    g = syn.KITTI
+    v, c, n = orc.voxelize(f["points"], g["point_cloud_range"], g["voxel_size"], 5, 16000)
+    assert v.shape[0] == 5000
+    idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+    rs = np.random.default_rng(0)
+    weights, bn = {}, {}
+    for name, cin, cout, ks, _st, _pd, _t, _key in orc.backbone8x_spec(4):
+        weights[name] = (rs.standard_normal((cout, *ks, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+        bn[name] = (np.ones(cout, np.float32), np.zeros(cout, np.float32), np.zeros(cout), np.ones(cout))
+    out = orc.backbone8x_forward(orc.mean_vfe(v, n), idx, 1, [41, 1600, 1408], weights, bn)
+    assert out["conv1.0.0"][2] == [41, 1600, 1408]
+    assert out["conv2.2.0"][2] == [21, 800, 704]
+    assert out["conv3.2.0"][2] == [11, 400, 352]
+    assert out["conv4.2.0"][2] == [5, 200, 176]
+    assert out["conv_out.0"][2] == [2, 200, 176] and out["conv_out.0"][0].shape[1] == 128

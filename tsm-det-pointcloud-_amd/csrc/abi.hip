@@ -1,0 +1,16 @@
+// abi.hip — library-level entry points of libspx (error strings, ABI version).
+#include "spx_common.h"
+
+extern "C" const char* spx_strerror(int code) {
+  switch (code) {
+    case SPX_OK: return "ok";
+    case SPX_ERR_INVALID_ARG: return "invalid argument (null pointer, bad extent, kernel volume > SPX_MAX_KVOL, capacity too small)";
+    case SPX_ERR_WORKSPACE: return "workspace missing or smaller than the *_ws_bytes() answer";
+    case SPX_ERR_UNSUPPORTED: return "unsupported channel count or mode";
+    case SPX_ERR_LAUNCH: return "HIP kernel launch failed";
+    case SPX_ERR_TOO_LARGE: return "problem too large (rows >= 2^31 or grid cells >= 2^40)";
+    default: return "unknown spx error code";
+  }
+}
+
+extern "C" int spx_abi_version(void) { return SPX_ABI_VERSION; }

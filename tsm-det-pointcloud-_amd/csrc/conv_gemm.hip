@@ -1,0 +1,247 @@
+// conv_gemm.hip — sparse convolution forward / dgrad as an output-stationary implicit GEMM.
+//
+//   dst[o, :] = sum_k  src[pair[k][o], :] . W_k          (W_k : [c_src, c_dst])
+//
+// One wave owns 16*MT destination rows and ALL c_dst columns, so there is no atomic, no scatter and
+// no cross-wave reduction: each destination row is written exactly once, in a fixed summation order
+// (bitwise reproducible).  For every kernel offset k the wave
+//   1. reads its rows' source indices pair[k][rows] (coalesced 64 B),
+//   2. skips the offset entirely when no row of the wave has a neighbour there (wave-uniform ballot),
+//      and skips 16-row M-tiles that have none,
+//   3. gathers the source rows straight into the MFMA A-operand registers: lane (r, q) of a 16-row
+//      tile loads the q-th quarter of row r as 16-byte pieces, so the 4 lanes of a row read 64
+//      contiguous bytes per instruction,
+//   4. issues v_mfma_f32_16x16x4_f32 (exact fp32, the reference's precision: spconv fp32, no TF32).
+// The GEMM K axis is PERMUTED so that each lane's operand values are contiguous in memory:
+// k-step j of lane quarter q is source channel q*(c_src/4)+j.  The weights are pre-packed by
+// spx_pack_weight in exactly that order, lane-linear, so a B fragment is one coalesced 1 KiB read.
+//
+// Serves reference call sites pcdet/models/backbones_3d/spconv_backbone.py:86,93,98-100,105-107,
+// 112-114,121 (forward) and their autograd (dgrad) — spconv itself is not vendored.
+#include "spx_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline bool mfma_ok(int c) { return c == 16 || c == 32 || c == 64 || c == 128; }
+static inline bool use_mfma(int c_src, int c_dst) { return mfma_ok(c_src) && mfma_ok(c_dst); }
+
+// ---------------------------------------------------------------- weight packing
+// mode 0 (forward): src channel = ci, dst channel = co ; mode 1 (dgrad): src = co, dst = ci
+__device__ __forceinline__ float w_elem(const float* w, int cout, int K, int cin, int mode, int k, int cs, int cd) {
+  return mode == 0 ? w[((size_t)cd * K + k) * cin + cs] : w[((size_t)cs * K + k) * cin + cd];
+}
+
+// MFMA order: [k][nt][jg][lane][e]; lane = 16q + c ; k-step j = 4jg + e ; cs = q*(CS/4) + j ; cd = 16nt + c
+__global__ void k_pack_mfma(const float* __restrict__ w, int cout, int K, int cin, int mode, int CS, int CD,
+                            float* __restrict__ out) {
+  int total = K * CS * CD;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int e = t & 3, lane = (t >> 2) & 63;
+  int rest = t >> 8;
+  int JG = CS / 16, NT = CD / 16;
+  int jg = rest % JG;
+  rest /= JG;
+  int nt = rest % NT;
+  int k = rest / NT;
+  int q = lane >> 4, c = lane & 15;
+  int cs = q * (CS / 4) + 4 * jg + e, cd = 16 * nt + c;
+  out[t] = w_elem(w, cout, K, cin, mode, k, cs, cd);
+}
+
+// plain order [k][cs][cd]
+__global__ void k_pack_plain(const float* __restrict__ w, int cout, int K, int cin, int mode, int CS, int CD,
+                             float* __restrict__ out) {
+  int total = K * CS * CD;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int cd = t % CD, cs = (t / CD) % CS, k = t / (CD * CS);
+  out[t] = w_elem(w, cout, K, cin, mode, k, cs, cd);
+}
+
+// ---------------------------------------------------------------- MFMA implicit GEMM
+template <int CS, int CD, int MT>
+__global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ src, const float* __restrict__ wp,
+                                                   const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
+                                                   int64_t n, const int64_t* d_n, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, int relu,
+                                                   float* __restrict__ dst) {
+  constexpr int NT = CD / 16;
+  constexpr int JG = CS / 16;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t nlive = spx_live_n(d_n, n);
+  const int64_t row_base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * MT);
+  if (row_base >= nlive) return;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+
+  for (int k = 0; k < K; ++k) {
+    const int32_t* prow = pair + (int64_t)(flip ? K - 1 - k : k) * ld;
+    int32_t id[MT];
+    bool mv[MT];
+    bool any = false;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      int64_t row = row_base + 16 * m + r;
+      id[m] = row < nlive ? prow[row] : -1;
+      mv[m] = __ballot(id[m] >= 0) != 0ull;
+      any |= mv[m];
+    }
+    if (!any) continue;  // wave-uniform
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg) {
+      f32x4 b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = wp4[((size_t)(k * NT + nt) * JG + jg) * 64 + lane];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (!mv[m]) continue;  // wave-uniform
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (id[m] >= 0)
+          a = *reinterpret_cast<const f32x4*>(src + (size_t)id[m] * CS + q * (CS / 4) + 4 * jg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[nt][e], acc[m][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: C layout col = lane&15, row = 4*(lane>>4) + e ; optional y = acc*scale + shift, ReLU
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = 16 * nt + r;
+    const float sc = scale ? scale[col] : 1.0f;
+    const float sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int64_t row = row_base + 16 * m + 4 * q + e;
+        if (row < nlive) {
+          float v = acc[m][nt][e];
+          if (scale || shift) v = v * sc + sh;
+          if (relu) v = v > 0.f ? v : 0.f;
+          dst[row * CD + col] = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------- VALU fallback (any channel counts)
+// thread = (row, cd); weights in plain [k][cs][cd] order.  Used for conv_input (c_src = 4 or 5) and
+// for channel counts the MFMA kernels do not tile.
+__global__ void k_conv_valu(const float* __restrict__ src, int CS, const float* __restrict__ wp, int CD,
+                            const int32_t* __restrict__ pair, int64_t ld, int K, int flip, int64_t n,
+                            const int64_t* d_n, const float* __restrict__ scale, const float* __restrict__ shift,
+                            int relu, float* __restrict__ dst) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = t / CD;
+  int cd = (int)(t % CD);
+  if (row >= spx_live_n(d_n, n)) return;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    int32_t id = pair[(int64_t)(flip ? K - 1 - k : k) * ld + row];
+    if (id < 0) continue;
+    const float* x = src + (size_t)id * CS;
+    const float* ww = wp + (size_t)k * CS * CD + cd;
+    for (int cs = 0; cs < CS; ++cs) acc = fmaf(x[cs], ww[(size_t)cs * CD], acc);
+  }
+  if (scale || shift) acc = acc * (scale ? scale[cd] : 1.f) + (shift ? shift[cd] : 0.f);
+  if (relu) acc = acc > 0.f ? acc : 0.f;
+  dst[row * CD + cd] = acc;
+}
+
+template <int CS, int CD>
+static int launch_mfma(const float* src, const float* wp, const int32_t* pair, int64_t ld, int K, int flip, int64_t n,
+                       const int64_t* d_n, const float* scale, const float* shift, int relu, float* dst,
+                       hipStream_t s) {
+  // rows per wave = 16*MT: larger MT amortises the weight fragment over more rows, smaller MT gives
+  // more waves.  Keep >= ~8 waves per CU (2048 waves) when the problem allows it.
+  int64_t waves4 = (n + 63) / 64, waves2 = (n + 31) / 32;
+  if (CD <= 64 && waves4 >= 2048) {
+    unsigned nb = (unsigned)((waves4 + 3) / 4);
+    hipLaunchKernelGGL((k_conv_mfma<CS, CD, 4>), dim3(nb), dim3(256), 0, s, src, wp, pair, ld, K, flip, n, d_n, scale,
+                       shift, relu, dst);
+  } else if (waves2 >= 1024 || CD > 64) {
+    unsigned nb = (unsigned)((waves2 + 3) / 4);
+    hipLaunchKernelGGL((k_conv_mfma<CS, CD, 2>), dim3(nb), dim3(256), 0, s, src, wp, pair, ld, K, flip, n, d_n, scale,
+                       shift, relu, dst);
+  } else {
+    int64_t waves1 = (n + 15) / 16;
+    unsigned nb = (unsigned)((waves1 + 3) / 4);
+    hipLaunchKernelGGL((k_conv_mfma<CS, CD, 1>), dim3(nb), dim3(256), 0, s, src, wp, pair, ld, K, flip, n, d_n, scale,
+                       shift, relu, dst);
+  }
+  return SPX_OK;
+}
+
+}  // namespace
+
+extern "C" int spx_pack_weight(const float* w, int cout, int kvol, int cin, int mode, float* packed,
+                               spx_stream_t stream) {
+  if (!w || !packed || cout <= 0 || cin <= 0 || kvol <= 0 || kvol > SPX_MAX_KVOL || (mode != 0 && mode != 1))
+    return SPX_ERR_INVALID_ARG;
+  int CS = mode == 0 ? cin : cout, CD = mode == 0 ? cout : cin;
+  int total = kvol * CS * CD;
+  unsigned nb = (unsigned)((total + 255) / 256);
+  if (use_mfma(CS, CD))
+    hipLaunchKernelGGL(k_pack_mfma, dim3(nb), dim3(256), 0, spx_s(stream), w, cout, kvol, cin, mode, CS, CD, packed);
+  else
+    hipLaunchKernelGGL(k_pack_plain, dim3(nb), dim3(256), 0, spx_s(stream), w, cout, kvol, cin, mode, CS, CD, packed);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}
+
+#define SPX_MFMA_CASE(A, B)                                                                                    \
+  if (c_src == A && c_dst == B) {                                                                              \
+    launch_mfma<A, B>(src, w_packed, pair, pair_ld, kvol, flip_k, n_dst, d_n_dst, scale, shift, relu, dst, s); \
+    SPX_CHECK_LAUNCH();                                                                                        \
+    return SPX_OK;                                                                                             \
+  }
+
+extern "C" int spx_conv_gemm(const float* src, int c_src, const float* w_packed, int c_dst, int kvol, int flip_k,
+                             const int32_t* pair, int64_t pair_ld, int64_t n_dst, const int64_t* d_n_dst,
+                             const float* scale, const float* shift, int relu, float* dst, spx_stream_t stream) {
+  if (!src || !w_packed || !pair || !dst || c_src <= 0 || c_dst <= 0 || kvol <= 0 || kvol > SPX_MAX_KVOL ||
+      n_dst < 0 || pair_ld < n_dst)
+    return SPX_ERR_INVALID_ARG;
+  if (n_dst >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
+  if (n_dst == 0) return SPX_OK;
+  hipStream_t s = spx_s(stream);
+  if (use_mfma(c_src, c_dst)) {
+    SPX_MFMA_CASE(16, 16)
+    SPX_MFMA_CASE(16, 32)
+    SPX_MFMA_CASE(32, 16)
+    SPX_MFMA_CASE(32, 32)
+    SPX_MFMA_CASE(32, 64)
+    SPX_MFMA_CASE(64, 32)
+    SPX_MFMA_CASE(64, 64)
+    SPX_MFMA_CASE(64, 128)
+    SPX_MFMA_CASE(128, 64)
+    SPX_MFMA_CASE(128, 128)
+    SPX_MFMA_CASE(16, 64)
+    SPX_MFMA_CASE(64, 16)
+    SPX_MFMA_CASE(32, 128)
+    SPX_MFMA_CASE(128, 32)
+    SPX_MFMA_CASE(16, 128)
+    SPX_MFMA_CASE(128, 16)
+    return SPX_ERR_UNSUPPORTED;  // unreachable: mfma_ok() admits exactly the 16 pairs above
+  }
+  int64_t total = n_dst * c_dst;
+  unsigned nb = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(k_conv_valu, dim3(nb), dim3(256), 0, s, src, c_src, w_packed, c_dst, pair, pair_ld, kvol, flip_k,
+                     n_dst, d_n_dst, scale, shift, relu, dst);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}

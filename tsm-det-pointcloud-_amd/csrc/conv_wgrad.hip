@@ -1,0 +1,170 @@
+// conv_wgrad.hip — weight gradient of the sparse convolution.
+//
+//   dw[co][k][ci] = sum_o dout[o, co] * in[pair[k][o], ci]
+//
+// The reduction axis (rule pairs of one offset k) is the MFMA K axis, so it can be COMPACTED: each wave
+// scans 64 rule entries at a time, ballot-compacts the valid (input row, output row) pairs into a
+// per-wave LDS queue and feeds v_mfma_f32_16x16x4_f32 four valid pairs per instruction — invalid pairs
+// cost nothing, which matters because 50-90 % of a submanifold rulebook is -1.
+//   A[i = ci][kk = pair p] = in  [src_row(p)][ci]     (16 lanes read 64 contiguous bytes of a row)
+//   B[kk = pair p][j = co] = dout[dst_row(p)][co]
+// grid = (S row-chunks, K offsets), one wave per block; each block owns a [cin, cout] accumulator for its
+// (chunk, offset) and writes it to a partial slab; a second kernel sums the S partials in fixed order
+// (no float atomics: bitwise reproducible) and emits the reference parameter layout [Cout][K][Cin].
+//
+// Serves the autograd of reference call sites spconv_backbone.py:86-121, triggered by loss.backward()
+// at tools/train_utils/train_utils.py:53.
+#include "spx_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int wgrad_splits(int64_t n) {
+  int64_t s = n / 256;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+template <int MI, int NJ>
+__global__ __launch_bounds__(64) void k_wgrad_mfma(const float* __restrict__ in, int cin,
+                                                   const float* __restrict__ dout, int cout,
+                                                   const int32_t* __restrict__ pair, int64_t ld, int64_t n,
+                                                   const int64_t* d_n, int64_t chunk, float* __restrict__ slab) {
+  __shared__ int32_t q_src[64];
+  __shared__ int32_t q_dst[64];
+  const int lane = threadIdx.x;
+  const int c = lane & 15, q = lane >> 4;
+  const int k = blockIdx.y, K = gridDim.y;
+  const int64_t nlive = spx_live_n(d_n, n);
+  int64_t r0 = (int64_t)blockIdx.x * chunk;
+  int64_t r1 = r0 + chunk < nlive ? r0 + chunk : nlive;
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int32_t* prow = pair + (int64_t)k * ld;
+  for (int64_t base = r0; base < r1; base += 64) {
+    int64_t row = base + lane;
+    int32_t id = row < r1 ? prow[row] : -1;
+    unsigned long long mask = __ballot(id >= 0);
+    if (mask == 0ull) continue;
+    int nvalid = __popcll(mask);
+    int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (id >= 0) {
+      q_src[rank] = id;
+      q_dst[rank] = (int32_t)row;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int st = 0; st * 4 < nvalid; ++st) {
+      int p = 4 * st + q;
+      bool has = p < nvalid;
+      int32_t sid = has ? q_src[p] : 0;
+      int32_t did = has ? q_dst[p] : 0;
+      float a[MI], b[NJ];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        int ci = 16 * mi + c;
+        a[mi] = (has && ci < cin) ? in[(size_t)sid * cin + ci] : 0.f;
+      }
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+        int co = 16 * nj + c;
+        b[nj] = (has && co < cout) ? dout[(size_t)did * cout + co] : 0.f;
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // partial[s][k][ci][co]; C layout: row(ci) = 16mi + 4q + e, col(co) = 16nj + c
+  float* out = slab + ((size_t)blockIdx.x * K + k) * cin * cout;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int ci = 16 * mi + 4 * q + e, co = 16 * nj + c;
+        if (ci < cin && co < cout) out[(size_t)ci * cout + co] = acc[mi][nj][e];
+      }
+}
+
+// dw[co][k][ci] = sum_s slab[s][k][ci][co]   (fixed order over s)
+__global__ void k_wgrad_reduce(const float* __restrict__ slab, int S, int K, int cin, int cout,
+                               float* __restrict__ dw) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int per = cin * cout;
+  if (t >= K * per) return;
+  int co = t % cout, ci = (t / cout) % cin, k = t / per;
+  float s = 0.f;
+  for (int j = 0; j < S; ++j) s += slab[((size_t)j * K + k) * per + (size_t)ci * cout + co];
+  dw[((size_t)co * K + k) * cin + ci] = s;
+}
+
+}  // namespace
+
+extern "C" size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n_out) {
+  return spx_align((size_t)wgrad_splits(n_out) * kvol * cin * cout * sizeof(float));
+}
+
+#define SPX_WG_CASE(A, B)                                                                                          \
+  if (MI == A && NJ == B) {                                                                                        \
+    hipLaunchKernelGGL((k_wgrad_mfma<A, B>), dim3(S, kvol), dim3(64), 0, s, in, cin, dout, cout, pair, pair_ld, n_out, \
+                       d_n_out, chunk, slab);                                                                      \
+    launched = true;                                                                                               \
+  }
+
+extern "C" int spx_conv_wgrad(const float* in, int cin, const float* dout, int cout, int kvol, const int32_t* pair,
+                              int64_t pair_ld, int64_t n_out, const int64_t* d_n_out, float* dw, void* ws,
+                              size_t ws_bytes, spx_stream_t stream) {
+  if (!in || !dout || !pair || !dw || cin <= 0 || cout <= 0 || kvol <= 0 || kvol > SPX_MAX_KVOL || n_out < 0 ||
+      pair_ld < n_out)
+    return SPX_ERR_INVALID_ARG;
+  if (cin > 128 || cout > 128) return SPX_ERR_UNSUPPORTED;
+  if (n_out >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
+  if (!ws || ws_bytes < spx_conv_wgrad_ws_bytes(cin, cout, kvol, n_out)) return SPX_ERR_WORKSPACE;
+  hipStream_t s = spx_s(stream);
+  if (n_out == 0) {
+    (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cout * kvol * cin, s);
+    return SPX_OK;
+  }
+  int S = wgrad_splits(n_out);
+  int64_t chunk = ((n_out + S - 1) / S + 63) / 64 * 64;
+  float* slab = reinterpret_cast<float*>(ws);
+  int MI = (cin + 15) / 16, NJ = (cout + 15) / 16;
+  if (MI == 3) MI = 4;
+  if (MI > 4) MI = 8;
+  if (NJ == 3) NJ = 4;
+  if (NJ > 4) NJ = 8;
+  bool launched = false;
+  SPX_WG_CASE(1, 1)
+  SPX_WG_CASE(1, 2)
+  SPX_WG_CASE(1, 4)
+  SPX_WG_CASE(1, 8)
+  SPX_WG_CASE(2, 1)
+  SPX_WG_CASE(2, 2)
+  SPX_WG_CASE(2, 4)
+  SPX_WG_CASE(2, 8)
+  SPX_WG_CASE(4, 1)
+  SPX_WG_CASE(4, 2)
+  SPX_WG_CASE(4, 4)
+  SPX_WG_CASE(4, 8)
+  SPX_WG_CASE(8, 1)
+  SPX_WG_CASE(8, 2)
+  SPX_WG_CASE(8, 4)
+  SPX_WG_CASE(8, 8)
+  if (!launched) return SPX_ERR_UNSUPPORTED;
+  int total = kvol * cin * cout;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, s, slab, S, kvol, cin, cout, dw);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}

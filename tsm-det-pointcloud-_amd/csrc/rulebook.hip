@@ -1,0 +1,373 @@
+// rulebook.hip — index arithmetic of the sparse-conv hot path (integer work, HBM/latency bound).
+//
+//  * submanifold rulebook  (SURVEY.md §8a row a7): open-addressing hash of 64-bit linear voxel keys,
+//    one probe per (output row, kernel offset), rows of one offset written coalesced, per-offset pair
+//    counts by wave ballot + one atomic per wave.
+//  * regular / strided rulebook (row a8): NO hash and NO sort.  The output grid is small (stride >= 1
+//    of an already sparse grid), so candidates are marked in a BITMAP over output cells; a popcount
+//    prefix-sum over the bitmap words gives every active cell its rank, and rank order IS the
+//    canonical ascending-linear-key order.  Pair tables are then filled input-driven:
+//    rank(o_key(i,k)) is one word load + one popcount.
+//
+// Replaces the indice-pair builders inside spconv.pytorch.{SubMConv3d,SparseConv3d}.forward, reference
+// call sites pcdet/models/backbones_3d/spconv_backbone.py:86-122 (spconv itself is not vendored).
+#include "spx_common.h"
+
+namespace {
+
+constexpr uint64_t kEmpty = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------ hash (subm)
+
+struct HashTable {
+  uint64_t* keys;
+  int32_t* vals;
+  int log2size;
+};
+
+static inline int64_t hash_slots(int64_t n) {
+  int64_t s = 1024;
+  while (s < 2 * n) s <<= 1;
+  return s;
+}
+static inline int ilog2(int64_t s) {
+  int l = 0;
+  while ((int64_t(1) << l) < s) ++l;
+  return l;
+}
+
+__global__ void k_hash_insert(const int32_t* __restrict__ idx, int64_t n, const int64_t* d_n, int batch, Int3 shape,
+                              HashTable t) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= spx_live_n(d_n, n)) return;
+  int4 c = reinterpret_cast<const int4*>(idx)[i];
+  if ((unsigned)c.x >= (unsigned)batch || (unsigned)c.y >= (unsigned)shape.v[0] ||
+      (unsigned)c.z >= (unsigned)shape.v[1] || (unsigned)c.w >= (unsigned)shape.v[2])
+    return;  // out-of-grid rows never become neighbours
+  uint64_t key = (uint64_t)spx_lin_key(c.x, c.y, c.z, c.w, shape);
+  uint64_t mask = (1ull << t.log2size) - 1;
+  uint64_t slot = spx_hash64(key) >> (64 - t.log2size);
+  for (;;) {
+    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.keys[slot]), kEmpty, key);
+    if (old == kEmpty || old == key) {
+      atomicMin(&t.vals[slot], (int32_t)i);  // duplicates: smallest row wins (deterministic)
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ int32_t hash_find(const HashTable& t, uint64_t key) {
+  uint64_t mask = (1ull << t.log2size) - 1;
+  uint64_t slot = spx_hash64(key) >> (64 - t.log2size);
+  for (;;) {
+    uint64_t k = t.keys[slot];
+    if (k == key) return t.vals[slot];
+    if (k == kEmpty) return -1;
+    slot = (slot + 1) & mask;
+  }
+}
+
+// grid (ceil(n/256), K): one probe per (row, offset); rows of one offset are contiguous -> coalesced stores
+__global__ void k_subm_probe(const int32_t* __restrict__ idx, int64_t n, const int64_t* d_n, Int3 shape, Int3 ks,
+                             Int3 dil, HashTable t, int32_t* __restrict__ pair, int64_t ld, int32_t* cnt) {
+  int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int k = blockIdx.y;
+  int kx = k % ks.v[2], ky = (k / ks.v[2]) % ks.v[1], kz = k / (ks.v[2] * ks.v[1]);
+  int32_t r = -1;
+  bool live = o < spx_live_n(d_n, n);
+  if (live) {
+    int4 c = reinterpret_cast<const int4*>(idx)[o];
+    int z = c.y + (kz - ks.v[0] / 2) * dil.v[0];
+    int y = c.z + (ky - ks.v[1] / 2) * dil.v[1];
+    int x = c.w + (kx - ks.v[2] / 2) * dil.v[2];
+    if ((unsigned)z < (unsigned)shape.v[0] && (unsigned)y < (unsigned)shape.v[1] &&
+        (unsigned)x < (unsigned)shape.v[2])
+      r = hash_find(t, (uint64_t)spx_lin_key(c.x, z, y, x, shape));
+    pair[(int64_t)k * ld + o] = r;
+  }
+  if (cnt != nullptr) {
+    unsigned long long m = __ballot(r >= 0);
+    if (spx_lane() == 0 && m) atomicAdd(&cnt[k], __popcll(m));
+  }
+}
+
+// ------------------------------------------------------------------------------------ bitmap rank (strided)
+
+struct ConvGeom {
+  Int3 in_shape, out_shape, ks, stride, pad, dil;
+};
+
+// output linear key of (input voxel c, offset k) or -1
+__device__ __forceinline__ int64_t cand_key(const int4& c, int k, const ConvGeom& g) {
+  int kx = k % g.ks.v[2], ky = (k / g.ks.v[2]) % g.ks.v[1], kz = k / (g.ks.v[2] * g.ks.v[1]);
+  int nz = c.y + g.pad.v[0] - kz * g.dil.v[0];
+  int ny = c.z + g.pad.v[1] - ky * g.dil.v[1];
+  int nx = c.w + g.pad.v[2] - kx * g.dil.v[2];
+  if (nz < 0 || ny < 0 || nx < 0) return -1;
+  int oz = nz / g.stride.v[0], oy = ny / g.stride.v[1], ox = nx / g.stride.v[2];
+  if (oz * g.stride.v[0] != nz || oy * g.stride.v[1] != ny || ox * g.stride.v[2] != nx) return -1;
+  if (oz >= g.out_shape.v[0] || oy >= g.out_shape.v[1] || ox >= g.out_shape.v[2]) return -1;
+  return spx_lin_key(c.x, oz, oy, ox, g.out_shape);
+}
+
+__device__ __forceinline__ bool in_grid(const int4& c, int batch, const Int3& s) {
+  return (unsigned)c.x < (unsigned)batch && (unsigned)c.y < (unsigned)s.v[0] && (unsigned)c.z < (unsigned)s.v[1] &&
+         (unsigned)c.w < (unsigned)s.v[2];
+}
+
+__global__ void k_mark(const int32_t* __restrict__ idx, int64_t n, const int64_t* d_n, int batch, ConvGeom g,
+                       uint64_t* bits) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= spx_live_n(d_n, n)) return;
+  int4 c = reinterpret_cast<const int4*>(idx)[i];
+  if (!in_grid(c, batch, g.in_shape)) return;
+  int64_t key = cand_key(c, blockIdx.y, g);
+  if (key < 0) return;
+  atomicOr(reinterpret_cast<unsigned long long*>(&bits[key >> 6]), 1ull << (key & 63));
+}
+
+constexpr int kWordsPerThread = 8;
+constexpr int kWordsPerBlock = kBlock * kWordsPerThread;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+  // 256 threads = 4 waves.  wave-level inclusive scan by shuffles, then combine through LDS.
+  __shared__ uint32_t wsum[4];
+  int lane = spx_lane(), wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  if (total) *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ void k_scan_blocksum(const uint64_t* __restrict__ bits, int64_t nwords, uint32_t* blocksum) {
+  int64_t w0 = (int64_t)blockIdx.x * kWordsPerBlock + (int64_t)threadIdx.x * kWordsPerThread;
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < kWordsPerThread; ++j)
+    if (w0 + j < nwords) s += __popcll(bits[w0 + j]);
+  uint32_t total;
+  block_exclusive_scan(s, &total);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of blocksum in place, total -> d_n_out
+__global__ void k_scan_top(uint32_t* blocksum, int64_t nblk, int64_t* d_n_out) {
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nblk; base += kBlock) {
+    int64_t j = base + threadIdx.x;
+    uint32_t v = j < nblk ? blocksum[j] : 0;
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(v, &total);
+    uint32_t carry = carry_s;
+    if (j < nblk) blocksum[j] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *d_n_out = (int64_t)carry_s;
+}
+
+__global__ void k_scan_expand(const uint64_t* __restrict__ bits, int64_t nwords, const uint32_t* __restrict__ blocksum,
+                              uint32_t* __restrict__ prefix, Int3 out_shape, int32_t* __restrict__ out_idx,
+                              int64_t cap) {
+  int64_t w0 = (int64_t)blockIdx.x * kWordsPerBlock + (int64_t)threadIdx.x * kWordsPerThread;
+  uint64_t wv[kWordsPerThread];
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < kWordsPerThread; ++j) {
+    wv[j] = (w0 + j < nwords) ? bits[w0 + j] : 0ull;
+    s += __popcll(wv[j]);
+  }
+  uint32_t run = blocksum[blockIdx.x] + block_exclusive_scan(s, nullptr);
+#pragma unroll
+  for (int j = 0; j < kWordsPerThread; ++j) {
+    if (w0 + j >= nwords) break;
+    prefix[w0 + j] = run;
+    uint64_t m = wv[j];
+    while (m) {
+      int b = __ffsll((unsigned long long)m) - 1;
+      m &= m - 1;
+      int64_t key = ((w0 + j) << 6) + b;
+      if ((int64_t)run < cap) {
+        int x = (int)(key % out_shape.v[2]);
+        int64_t t = key / out_shape.v[2];
+        int y = (int)(t % out_shape.v[1]);
+        t /= out_shape.v[1];
+        int z = (int)(t % out_shape.v[0]);
+        int bb = (int)(t / out_shape.v[0]);
+        reinterpret_cast<int4*>(out_idx)[run] = make_int4(bb, z, y, x);
+      }
+      ++run;
+    }
+  }
+}
+
+// pair_fwd[k][0..n_out) = -1, launched at capacity, guarded by the device-side count
+__global__ void k_fill_neg1(int32_t* pair, int64_t ld, const int64_t* d_n_out) {
+  int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int64_t n = *d_n_out;
+  if (n > ld) n = ld;
+  if (o < n) pair[(int64_t)blockIdx.y * ld + o] = -1;
+}
+
+__global__ void k_conv_pairs(const int32_t* __restrict__ idx, int64_t n, const int64_t* d_n, int batch, ConvGeom g,
+                             const uint64_t* __restrict__ bits, const uint32_t* __restrict__ prefix,
+                             int32_t* __restrict__ pair_fwd, int64_t cap, int32_t* __restrict__ pair_bwd,
+                             int32_t* cnt) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int k = blockIdx.y;
+  int32_t row = -1;
+  bool live = i < spx_live_n(d_n, n);
+  if (live) {
+    int4 c = reinterpret_cast<const int4*>(idx)[i];
+    int64_t key = in_grid(c, batch, g.in_shape) ? cand_key(c, k, g) : -1;
+    if (key >= 0) {
+      uint64_t w = bits[key >> 6];
+      uint32_t r = prefix[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1));
+      if ((int64_t)r < cap) {
+        row = (int32_t)r;
+        pair_fwd[(int64_t)k * cap + r] = (int32_t)i;
+      }
+    }
+    pair_bwd[(int64_t)k * n + i] = row;
+  }
+  if (cnt != nullptr) {
+    unsigned long long m = __ballot(row >= 0);
+    if (spx_lane() == 0 && m) atomicAdd(&cnt[k], __popcll(m));
+  }
+}
+
+static inline int64_t cells_of(int batch, const int32_t* s) { return (int64_t)batch * s[0] * s[1] * s[2]; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ C ABI
+
+extern "C" size_t spx_subm_rulebook_ws_bytes(int64_t n) {
+  int64_t s = hash_slots(n < 1 ? 1 : n);
+  return spx_align((size_t)s * 8) + spx_align((size_t)s * 4);
+}
+
+extern "C" int spx_subm_rulebook(const int32_t* idx, int64_t n, const int64_t* d_n, int batch, const int32_t* shape,
+                                 const int32_t* ksize, const int32_t* dil, int32_t* pair, int64_t pair_ld,
+                                 int32_t* cnt, void* ws, size_t ws_bytes, spx_stream_t stream) {
+  if (!idx || !shape || !ksize || !dil || !pair || n < 0 || batch <= 0 || pair_ld < n) return SPX_ERR_INVALID_ARG;
+  int K = ksize[0] * ksize[1] * ksize[2];
+  if (K <= 0 || K > SPX_MAX_KVOL) return SPX_ERR_INVALID_ARG;
+  if (n >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
+  if (!ws || ws_bytes < spx_subm_rulebook_ws_bytes(n)) return SPX_ERR_WORKSPACE;
+  hipStream_t s = spx_s(stream);
+  if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * K, s);
+  if (n == 0) return SPX_OK;
+  int64_t slots = hash_slots(n);
+  HashTable t;
+  t.keys = reinterpret_cast<uint64_t*>(ws);
+  t.vals = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + spx_align((size_t)slots * 8));
+  t.log2size = ilog2(slots);
+  (void)hipMemsetAsync(t.keys, 0xFF, (size_t)slots * 8, s);
+  (void)hipMemsetAsync(t.vals, 0x7F, (size_t)slots * 4, s);
+  unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_hash_insert, dim3(nb), dim3(kBlock), 0, s, idx, n, d_n, batch, spx_i3(shape), t);
+  hipLaunchKernelGGL(k_subm_probe, dim3(nb, K), dim3(kBlock), 0, s, idx, n, d_n, spx_i3(shape), spx_i3(ksize),
+                     spx_i3(dil), t, pair, pair_ld, cnt);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}
+
+extern "C" int64_t spx_conv_out_cap(int64_t n_in, int batch, const int32_t* out_shape, const int32_t* ksize,
+                                    const int32_t* stride) {
+  int64_t per = 1;
+  for (int j = 0; j < 3; ++j) per *= (ksize[j] + stride[j] - 1) / stride[j];
+  int64_t a = per * n_in, b = cells_of(batch, out_shape);
+  int64_t c = a < b ? a : b;
+  return c < 1 ? 1 : c;
+}
+
+namespace {
+struct RbWs {
+  uint64_t* bits;
+  uint32_t* prefix;
+  uint32_t* blocksum;
+  int64_t nwords, nblk;
+  size_t total;
+};
+static RbWs rb_layout(void* ws, int batch, const int32_t* out_shape) {
+  RbWs r;
+  int64_t cells = cells_of(batch, out_shape);
+  r.nwords = (cells + 63) / 64;
+  r.nblk = (r.nwords + kWordsPerBlock - 1) / kWordsPerBlock;
+  char* p = reinterpret_cast<char*>(ws);
+  size_t o = 0;
+  r.bits = reinterpret_cast<uint64_t*>(p + o);
+  o += spx_align((size_t)r.nwords * 8);
+  r.prefix = reinterpret_cast<uint32_t*>(p + o);
+  o += spx_align((size_t)r.nwords * 4);
+  r.blocksum = reinterpret_cast<uint32_t*>(p + o);
+  o += spx_align((size_t)(r.nblk + 1) * 4);
+  r.total = o;
+  return r;
+}
+}  // namespace
+
+extern "C" size_t spx_conv_rulebook_ws_bytes(int64_t n_in, int batch, const int32_t* out_shape) {
+  (void)n_in;
+  return rb_layout(nullptr, batch, out_shape).total;
+}
+
+extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t* d_n_in, int batch,
+                                 const int32_t* in_shape, const int32_t* out_shape, const int32_t* ksize,
+                                 const int32_t* stride, const int32_t* pad, const int32_t* dil, int32_t* out_idx,
+                                 int32_t* pair_fwd, int32_t* pair_bwd, int32_t* cnt, int64_t* d_n_out, int64_t cap,
+                                 void* ws, size_t ws_bytes, spx_stream_t stream) {
+  if (!idx || !in_shape || !out_shape || !ksize || !stride || !pad || !dil || !out_idx || !pair_fwd || !pair_bwd ||
+      !d_n_out || n_in < 0 || batch <= 0 || cap <= 0)
+    return SPX_ERR_INVALID_ARG;
+  int K = ksize[0] * ksize[1] * ksize[2];
+  if (K <= 0 || K > SPX_MAX_KVOL) return SPX_ERR_INVALID_ARG;
+  for (int j = 0; j < 3; ++j) {
+    if (stride[j] <= 0 || dil[j] <= 0 || pad[j] < 0 || in_shape[j] <= 0) return SPX_ERR_INVALID_ARG;
+    int expect = (in_shape[j] + 2 * pad[j] - dil[j] * (ksize[j] - 1) - 1) / stride[j] + 1;
+    if (out_shape[j] != expect || expect <= 0) return SPX_ERR_INVALID_ARG;
+  }
+  if (n_in >= (int64_t(1) << 31) || cap >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
+  if (cells_of(batch, out_shape) >= (int64_t(1) << 40)) return SPX_ERR_TOO_LARGE;
+  if (cap < spx_conv_out_cap(n_in, batch, out_shape, ksize, stride)) return SPX_ERR_INVALID_ARG;
+  if (!ws || ws_bytes < spx_conv_rulebook_ws_bytes(n_in, batch, out_shape)) return SPX_ERR_WORKSPACE;
+  hipStream_t s = spx_s(stream);
+  RbWs w = rb_layout(ws, batch, out_shape);
+  ConvGeom g;
+  g.in_shape = spx_i3(in_shape);
+  g.out_shape = spx_i3(out_shape);
+  g.ks = spx_i3(ksize);
+  g.stride = spx_i3(stride);
+  g.pad = spx_i3(pad);
+  g.dil = spx_i3(dil);
+  if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * K, s);
+  (void)hipMemsetAsync(w.bits, 0, (size_t)w.nwords * 8, s);
+  unsigned nb_in = (unsigned)((n_in + kBlock - 1) / kBlock);
+  if (n_in > 0) hipLaunchKernelGGL(k_mark, dim3(nb_in, K), dim3(kBlock), 0, s, idx, n_in, d_n_in, batch, g, w.bits);
+  hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, w.blocksum, w.nblk, d_n_out);
+  hipLaunchKernelGGL(k_scan_expand, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum, w.prefix,
+                     g.out_shape, out_idx, cap);
+  unsigned nb_cap = (unsigned)((cap + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_fill_neg1, dim3(nb_cap, K), dim3(kBlock), 0, s, pair_fwd, cap, d_n_out);
+  if (n_in > 0)
+    hipLaunchKernelGGL(k_conv_pairs, dim3(nb_in, K), dim3(kBlock), 0, s, idx, n_in, d_n_in, batch, g, w.bits, w.prefix,
+                       pair_fwd, cap, pair_bwd, cnt);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}

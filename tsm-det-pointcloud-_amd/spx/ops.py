@@ -1,0 +1,232 @@
+"""Tensor-level wrappers over the C ABI (include/spx.h).  torch is used for device memory and streams only.
+
+Every function here launches HIP kernels from libspx.so on torch's current stream; nothing is computed by
+torch ops and there is no CPU path (inputs must live on a GPU).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, f_arr, i3
+
+_WS = {}
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.SpxError("spx ops need GPU tensors (got a %s tensor): the sparse-conv hot path has no "
+                                "CPU fallback" % t.device)
+
+
+def workspace(device, nbytes):
+    """Grow-only scratch buffer per (device, stream); stream order makes back-to-back reuse safe."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def out_shape_of(in_shape, ksize, stride, pad, dil):
+    return [(int(i) + 2 * int(p) - int(d) * (int(k) - 1) - 1) // int(s) + 1
+            for i, k, s, p, d in zip(in_shape, ksize, stride, pad, dil)]
+
+
+class Rulebook(object):
+    """Indice pairs of one sparse conv (what spconv caches under `indice_key`).
+
+    pair      int32 [K, ld]   forward table: pair[k, o] = input row feeding output o at offset k (or -1)
+    pair_bwd  int32 [K, n_in] backward table (None for submanifold: the forward table is read at K-1-k)
+    """
+
+    def __init__(self, pair, ld, n_in, n_out, kvol, subm, out_indices, out_shape, in_shape, pair_bwd=None, cnt=None,
+                 ksize=None, stride=None, padding=None, dilation=None):
+        self.pair, self.ld, self.n_in, self.n_out, self.kvol, self.subm = pair, ld, n_in, n_out, kvol, subm
+        self.out_indices, self.out_shape, self.in_shape = out_indices, list(out_shape), list(in_shape)
+        self.pair_bwd, self.cnt = pair_bwd, cnt
+        self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
+
+
+# ------------------------------------------------------------------------------------------- voxelise
+
+def voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels, batch_size=1, batch_col=-1, xyz_col=0,
+             feat_col=0, num_features=None, want_voxels=True, want_mean=True):
+    """GPU hard voxelisation (+ fused MeanVFE).  Returns dict(voxels, coords[M,4], num_points, mean, M).
+
+    One host sync (reads M).  Semantics: include/spx.h §1 / SURVEY.md §8a row a1.
+    """
+    _need_gpu(points)
+    lib = _lib.load()
+    points = points.contiguous().float()
+    n, stride = points.shape
+    c = (stride - feat_col) if num_features is None else int(num_features)
+    rng = [float(x) for x in point_cloud_range]
+    vs = [float(x) for x in voxel_size]
+    grid = [int(round((rng[3 + j] - rng[j]) / vs[j])) for j in range(3)]
+    cap = max(1, min(n, batch_size * max_voxels))
+    dev = points.device
+    voxels = torch.empty((cap, max_points, c), dtype=torch.float32, device=dev) if want_voxels else None
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    mean = torch.empty((cap, c), dtype=torch.float32, device=dev) if want_mean else None
+    d_m = torch.zeros((1,), dtype=torch.int64, device=dev)
+    wsb = lib.spx_voxelize_ws_bytes(n, batch_size, max_points)
+    ws = workspace(dev, wsb)
+    check(lib.spx_voxelize(_ptr(points), n, stride, xyz_col, feat_col, c, batch_col, batch_size, f_arr(rng), f_arr(vs),
+                           i3(grid), max_points, max_voxels, _ptr(voxels), _ptr(coords), _ptr(num), _ptr(mean),
+                           _ptr(d_m), cap, _ptr(ws), wsb, _stream(points)), "spx_voxelize")
+    m = int(d_m.item())
+    return dict(voxels=None if voxels is None else voxels[:m], coords=coords[:m], num_points=num[:m],
+                mean=None if mean is None else mean[:m], num_voxels=m, grid_size=grid)
+
+
+def mean_vfe(voxels, num_points):
+    _need_gpu(voxels, num_points)
+    lib = _lib.load()
+    voxels = voxels.contiguous().float()
+    num = num_points.contiguous().to(torch.int32)
+    n, t, c = voxels.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=voxels.device)
+    check(lib.spx_mean_vfe(_ptr(voxels), _ptr(num), n, None, t, c, _ptr(out), _stream(voxels)), "spx_mean_vfe")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- rulebooks
+
+def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False):
+    _need_gpu(indices)
+    lib = _lib.load()
+    indices = indices.contiguous()
+    assert indices.dtype == torch.int32 and indices.shape[1] == 4
+    n = indices.shape[0]
+    K = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
+    dev = indices.device
+    ld = max(n, 1)
+    pair = torch.empty((K, ld), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((K,), dtype=torch.int32, device=dev) if want_cnt else None
+    wsb = lib.spx_subm_rulebook_ws_bytes(n)
+    ws = workspace(dev, wsb)
+    check(lib.spx_subm_rulebook(_ptr(indices), n, None, batch_size, i3(spatial_shape), i3(ksize), i3(dilation),
+                                _ptr(pair), ld, _ptr(cnt), _ptr(ws), wsb, _stream(indices)), "spx_subm_rulebook")
+    return Rulebook(pair, ld, n, n, K, True, indices, spatial_shape, spatial_shape, cnt=cnt, ksize=list(ksize),
+                    stride=[1, 1, 1], padding=[k // 2 for k in ksize], dilation=list(dilation))
+
+
+def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1), want_cnt=False):
+    """Regular sparse conv rulebook.  One host sync (reads n_out)."""
+    _need_gpu(indices)
+    lib = _lib.load()
+    indices = indices.contiguous()
+    assert indices.dtype == torch.int32 and indices.shape[1] == 4
+    n_in = indices.shape[0]
+    K = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
+    dev = indices.device
+    out_shape = out_shape_of(spatial_shape, ksize, stride, padding, dilation)
+    cap = int(lib.spx_conv_out_cap(n_in, batch_size, i3(out_shape), i3(ksize), i3(stride)))
+    out_idx = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    pair_fwd = torch.empty((K, cap), dtype=torch.int32, device=dev)
+    pair_bwd = torch.empty((K, max(n_in, 1)), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((K,), dtype=torch.int32, device=dev) if want_cnt else None
+    d_n = torch.zeros((1,), dtype=torch.int64, device=dev)
+    wsb = lib.spx_conv_rulebook_ws_bytes(n_in, batch_size, i3(out_shape))
+    ws = workspace(dev, wsb)
+    check(lib.spx_conv_rulebook(_ptr(indices), n_in, None, batch_size, i3(spatial_shape), i3(out_shape), i3(ksize),
+                                i3(stride), i3(padding), i3(dilation), _ptr(out_idx), _ptr(pair_fwd), _ptr(pair_bwd),
+                                _ptr(cnt), _ptr(d_n), cap, _ptr(ws), wsb, _stream(indices)), "spx_conv_rulebook")
+    n_out = int(d_n.item())
+    return Rulebook(pair_fwd, cap, n_in, n_out, K, False, out_idx[:n_out], out_shape, spatial_shape, pair_bwd=pair_bwd,
+                    cnt=cnt, ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation))
+
+
+# ------------------------------------------------------------------------------------------- arithmetic
+
+def pack_weight(weight, mode):
+    """weight [Cout, kz, ky, kx, Cin] (or [Cout, K, Cin]) -> MFMA operand order.  mode 0 fwd, 1 dgrad."""
+    _need_gpu(weight)
+    lib = _lib.load()
+    w = weight.detach().contiguous().float()
+    cout, cin = w.shape[0], w.shape[-1]
+    K = w.numel() // (cout * cin)
+    packed = torch.empty((K * cin * cout,), dtype=torch.float32, device=w.device)
+    check(lib.spx_pack_weight(_ptr(w), cout, K, cin, mode, _ptr(packed), _stream(w)), "spx_pack_weight")
+    return packed
+
+
+def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False):
+    _need_gpu(src, w_packed, pair)
+    lib = _lib.load()
+    src = src.contiguous()
+    assert src.dtype == torch.float32
+    dst = torch.empty((n_dst, c_dst), dtype=torch.float32, device=src.device)
+    if n_dst == 0:
+        return dst
+    if src.shape[0] == 0:
+        return dst.zero_()
+    check(lib.spx_conv_gemm(_ptr(src), src.shape[1], _ptr(w_packed), c_dst, kvol, int(bool(flip_k)), _ptr(pair), ld,
+                            n_dst, None, _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(dst), _stream(src)),
+          "spx_conv_gemm")
+    return dst
+
+
+def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
+    _need_gpu(feat_in, dout, pair)
+    lib = _lib.load()
+    feat_in = feat_in.contiguous()
+    dout = dout.contiguous()
+    cout, cin = wshape[0], wshape[-1]
+    K = 1
+    for s in wshape[1:-1]:
+        K *= int(s)
+    dw = torch.empty(tuple(wshape), dtype=torch.float32, device=dout.device)
+    if feat_in.shape[0] == 0 or n_out == 0:
+        return dw.zero_()
+    wsb = lib.spx_conv_wgrad_ws_bytes(cin, cout, K, n_out)
+    ws = workspace(dout.device, wsb)
+    check(lib.spx_conv_wgrad(_ptr(feat_in), cin, _ptr(dout), cout, K, _ptr(pair), ld, n_out, None, _ptr(dw), _ptr(ws),
+                             wsb, _stream(dout)), "spx_conv_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------------------------------- densify
+
+def densify(features, indices, batch_size, spatial_shape, channels_last=False):
+    """[N,C] -> logical [B,C,D,H,W].  channels_last=True stores it as [B,H,W,C,D] (see include/spx.h §5)."""
+    _need_gpu(features, indices)
+    lib = _lib.load()
+    features = features.contiguous()
+    n, c = features.shape
+    d, h, w = [int(s) for s in spatial_shape]
+    dev = features.device
+    if channels_last:
+        dense = torch.zeros((batch_size, h, w, c, d), dtype=torch.float32, device=dev)
+    else:
+        dense = torch.zeros((batch_size, c, d, h, w), dtype=torch.float32, device=dev)
+    check(lib.spx_densify(_ptr(features), _ptr(indices), n, None, c, batch_size, i3(spatial_shape),
+                          1 if channels_last else 0, _ptr(dense), _stream(features)), "spx_densify")
+    return dense.permute(0, 3, 4, 1, 2) if channels_last else dense
+
+
+def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False):
+    _need_gpu(ddense, indices)
+    lib = _lib.load()
+    n = indices.shape[0]
+    c = ddense.shape[1]
+    if channels_last:
+        dd = ddense.permute(0, 3, 4, 1, 2).contiguous()  # -> [B,H,W,C,D] storage
+    else:
+        dd = ddense.contiguous()
+    dfeat = torch.empty((n, c), dtype=torch.float32, device=ddense.device)
+    check(lib.spx_densify_bwd(_ptr(dd), _ptr(indices), n, None, c, batch_size, i3(spatial_shape),
+                              1 if channels_last else 0, _ptr(dfeat), _stream(ddense)), "spx_densify_bwd")
+    return dfeat
