@@ -264,7 +264,8 @@ extern "C" size_t spx_subm_rulebook_ws_bytes(int64_t n) {
 extern "C" int spx_subm_rulebook(const int32_t* idx, int64_t n, const int64_t* d_n, int batch, const int32_t* shape,
                                  const int32_t* ksize, const int32_t* dil, int32_t* pair, int64_t pair_ld,
                                  int32_t* cnt, void* ws, size_t ws_bytes, spx_stream_t stream) {
-  if (!idx || !shape || !ksize || !dil || !pair || n < 0 || batch <= 0 || pair_ld < n) return SPX_ERR_INVALID_ARG;
+  if ((!idx && n > 0) || !shape || !ksize || !dil || (!pair && n > 0) || n < 0 || batch <= 0 || pair_ld < n)
+    return SPX_ERR_INVALID_ARG;
   int K = ksize[0] * ksize[1] * ksize[2];
   if (K <= 0 || K > SPX_MAX_KVOL) return SPX_ERR_INVALID_ARG;
   if (n >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
@@ -332,7 +333,7 @@ extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t
                                  const int32_t* stride, const int32_t* pad, const int32_t* dil, int32_t* out_idx,
                                  int32_t* pair_fwd, int32_t* pair_bwd, int32_t* cnt, int64_t* d_n_out, int64_t cap,
                                  void* ws, size_t ws_bytes, spx_stream_t stream) {
-  if (!idx || !in_shape || !out_shape || !ksize || !stride || !pad || !dil || !out_idx || !pair_fwd || !pair_bwd ||
+  if ((!idx && n_in > 0) || !in_shape || !out_shape || !ksize || !stride || !pad || !dil || !out_idx || !pair_fwd || !pair_bwd ||
       !d_n_out || n_in < 0 || batch <= 0 || cap <= 0)
     return SPX_ERR_INVALID_ARG;
   int K = ksize[0] * ksize[1] * ksize[2];

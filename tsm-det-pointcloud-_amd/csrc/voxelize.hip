@@ -245,7 +245,7 @@ extern "C" int spx_voxelize(const float* points, int64_t n_points, int point_str
                             int max_points, int max_voxels, float* voxels, int32_t* coords, int32_t* num_points,
                             float* mean, int64_t* d_num_voxels, int64_t cap, void* ws, size_t ws_bytes,
                             spx_stream_t stream) {
-  if (!points || !range || !vsize || !grid || !coords || !num_points || !d_num_voxels || n_points < 0 ||
+  if ((!points && n_points > 0) || !range || !vsize || !grid || !coords || !num_points || !d_num_voxels || n_points < 0 ||
       point_stride <= 0 || c <= 0 || xyz_col < 0 || feat_col < 0 || xyz_col + 3 > point_stride ||
       feat_col + c > point_stride || batch_col >= point_stride || batch <= 0 || max_points <= 0 ||
       max_points > 64 || max_voxels <= 0 || cap <= 0)
