@@ -1,0 +1,5 @@
+from .spconv_backbone import VoxelBackBone8x
+
+__all__ = {
+    'VoxelBackBone8x': VoxelBackBone8x,
+}

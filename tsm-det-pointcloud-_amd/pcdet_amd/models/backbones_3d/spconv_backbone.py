@@ -1,0 +1,97 @@
+"""VoxelBackBone8x on libspx — same constructor, state_dict keys, batch_dict keys and attributes as the
+reference's pcdet/models/backbones_3d/spconv_backbone.py:77-194 (stage wiring :85-125, outputs :169-192).
+
+The 12 sparse convolutions (8 SubM k3, 3 strided k3 s2, 1 k(3,1,1) s(2,1,1)) run as hand-written HIP kernels;
+BatchNorm1d(eps=1e-3, momentum=0.01) + ReLU stay torch.nn modules so parameter names (`conv2.0.1.weight` ...)
+and train/eval behaviour are unchanged.
+"""
+from functools import partial
+
+import torch.nn as nn
+
+import spx as spconv
+
+from ...utils.spconv_utils import replace_feature  # noqa: F401  (API parity)
+
+
+def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type='subm',
+                   norm_fn=None, active=True):
+    if conv_type == 'subm':
+        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+    elif conv_type == 'spconv':
+        conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
+                                   indice_key=indice_key)
+    elif conv_type == 'inverseconv':
+        conv = spconv.SparseInverseConv3d(in_channels, out_channels, kernel_size, indice_key=indice_key, bias=False)
+    else:
+        raise NotImplementedError
+    layers = [conv, norm_fn(out_channels)]
+    if active:
+        layers.append(nn.ReLU())
+    return spconv.SparseSequential(*layers)
+
+
+class VoxelBackBone8x(nn.Module):
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        # (z, y, x) order with one extra z cell: 40 -> 41 so that three stride-2 stages give 41->21->11->5
+        self.sparse_shape = [int(grid_size[2]) + 1, int(grid_size[1]), int(grid_size[0])]
+
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key='subm1'),
+            norm_fn(16),
+            nn.ReLU(),
+        )
+        block = partial(post_act_block, norm_fn=norm_fn)
+        self.conv1 = spconv.SparseSequential(
+            block(16, 16, 3, padding=1, indice_key='subm1'),
+        )
+        self.conv2 = spconv.SparseSequential(
+            block(16, 32, 3, stride=2, padding=1, indice_key='spconv2', conv_type='spconv'),
+            block(32, 32, 3, padding=1, indice_key='subm2'),
+            block(32, 32, 3, padding=1, indice_key='subm2'),
+        )
+        self.conv3 = spconv.SparseSequential(
+            block(32, 64, 3, stride=2, padding=1, indice_key='spconv3', conv_type='spconv'),
+            block(64, 64, 3, padding=1, indice_key='subm3'),
+            block(64, 64, 3, padding=1, indice_key='subm3'),
+        )
+        self.conv4 = spconv.SparseSequential(
+            block(64, 64, 3, stride=2, padding=(0, 1, 1), indice_key='spconv4', conv_type='spconv'),
+            block(64, 64, 3, padding=1, indice_key='subm4'),
+            block(64, 64, 3, padding=1, indice_key='subm4'),
+        )
+        last_pad = self.model_cfg.get('last_pad', 0) if hasattr(self.model_cfg, 'get') else 0
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(64, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                indice_key='spconv_down2'),
+            norm_fn(128),
+            nn.ReLU(),
+        )
+        self.num_point_features = 128
+        self.backbone_channels = {'x_conv1': 16, 'x_conv2': 32, 'x_conv3': 64, 'x_conv4': 64, 'x_points_mean': 32,
+                                  'x_points_max': 32}
+
+    def forward(self, batch_dict):
+        """batch_dict in: voxel_features [N,C], voxel_coords [N,4] (b,z,y,x), batch_size.
+        out: encoded_spconv_tensor (+_stride 8), multi_scale_3d_features / _strides."""
+        voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
+        x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(),
+                                    spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        x = self.conv_input(x)
+        x_conv1 = self.conv1(x)
+        x_conv2 = self.conv2(x_conv1)
+        x_conv3 = self.conv3(x_conv2)
+        x_conv4 = self.conv4(x_conv3)
+        out = self.conv_out(x_conv4)  # [200, 176, 5] -> [200, 176, 2]
+
+        batch_dict['encoded_spconv_tensor'] = out
+        batch_dict['encoded_spconv_tensor_stride'] = 8
+        batch_dict['multi_scale_3d_features'] = {'x_conv1': x_conv1, 'x_conv2': x_conv2, 'x_conv3': x_conv3,
+                                                 'x_conv4': x_conv4, 'x_points_mean': x_conv2,
+                                                 'x_points_max': x_conv2}
+        batch_dict['multi_scale_3d_strides'] = {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8,
+                                                'x_points_mean': 2, 'x_points_max': 2}
+        return batch_dict

@@ -1,0 +1,7 @@
+from .mean_vfe import MeanVFE
+from .vfe_template import VFETemplate
+
+__all__ = {
+    'VFETemplate': VFETemplate,
+    'MeanVFE': MeanVFE,
+}

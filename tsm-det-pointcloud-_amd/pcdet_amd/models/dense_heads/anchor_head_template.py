@@ -1,0 +1,168 @@
+"""AnchorHeadTemplate (API and arithmetic of reference pcdet/models/dense_heads/anchor_head_template.py:11-276):
+anchors, target assignment, focal / smooth-L1 / direction losses, box decoding.  Device agnostic (anchors are
+buffers), and the loss dictionary holds 0-d tensors instead of .item() floats so no host sync happens per step."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ...utils import box_coder_utils, common_utils, loss_utils
+from .target_assigner.anchor_generator import AnchorGenerator
+from .target_assigner.axis_aligned_target_assigner import AxisAlignedTargetAssigner
+
+
+class AnchorHeadTemplate(nn.Module):
+    def __init__(self, model_cfg, num_class, class_names, grid_size, point_cloud_range, predict_boxes_when_training):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.class_names = class_names
+        self.predict_boxes_when_training = predict_boxes_when_training
+        self.use_multihead = self.model_cfg.get('USE_MULTIHEAD', False)
+
+        anchor_target_cfg = self.model_cfg.TARGET_ASSIGNER_CONFIG
+        self.box_coder = getattr(box_coder_utils, anchor_target_cfg.BOX_CODER)(
+            num_dir_bins=anchor_target_cfg.get('NUM_DIR_BINS', 6), **anchor_target_cfg.get('BOX_CODER_CONFIG', {}))
+
+        anchors, self.num_anchors_per_location = self.generate_anchors(
+            self.model_cfg.ANCHOR_GENERATOR_CONFIG, grid_size=grid_size, point_cloud_range=point_cloud_range,
+            anchor_ndim=self.box_coder.code_size)
+        self._n_anchor_sets = len(anchors)
+        for i, a in enumerate(anchors):
+            self.register_buffer('_anchors_%d' % i, a, persistent=False)
+        self.target_assigner = self.get_target_assigner(anchor_target_cfg)
+        self.forward_ret_dict = {}
+        self.build_losses(self.model_cfg.LOSS_CONFIG)
+
+    @property
+    def anchors(self):
+        return [getattr(self, '_anchors_%d' % i) for i in range(self._n_anchor_sets)]
+
+    @staticmethod
+    def generate_anchors(anchor_generator_cfg, grid_size, point_cloud_range, anchor_ndim=7):
+        gen = AnchorGenerator(anchor_range=point_cloud_range, anchor_generator_config=anchor_generator_cfg)
+        gs = np.asarray(grid_size)
+        feature_map_size = [gs[:2] // c['feature_map_stride'] for c in anchor_generator_cfg]
+        anchors_list, per_location = gen.generate_anchors(feature_map_size)
+        if anchor_ndim != 7:
+            anchors_list = [torch.cat((a, a.new_zeros([*a.shape[0:-1], anchor_ndim - 7])), dim=-1)
+                            for a in anchors_list]
+        return anchors_list, per_location
+
+    def get_target_assigner(self, anchor_target_cfg):
+        if anchor_target_cfg.NAME == 'AxisAlignedTargetAssigner':
+            return AxisAlignedTargetAssigner(model_cfg=self.model_cfg, class_names=self.class_names,
+                                             box_coder=self.box_coder, match_height=anchor_target_cfg.MATCH_HEIGHT)
+        raise NotImplementedError(anchor_target_cfg.NAME)
+
+    def build_losses(self, losses_cfg):
+        self.add_module('cls_loss_func', loss_utils.SigmoidFocalClassificationLoss(alpha=0.25, gamma=2.0))
+        reg_loss_name = losses_cfg.get('REG_LOSS_TYPE', None) or 'WeightedSmoothL1Loss'
+        self.add_module('reg_loss_func',
+                        getattr(loss_utils, reg_loss_name)(code_weights=losses_cfg.LOSS_WEIGHTS['code_weights']))
+        self.add_module('dir_loss_func', loss_utils.WeightedCrossEntropyLoss())
+
+    def assign_targets(self, gt_boxes):
+        """gt_boxes (B, M, 8)"""
+        return self.target_assigner.assign_targets(self.anchors, gt_boxes)
+
+    def _flat_anchors(self):
+        return torch.cat(self.anchors, dim=-3)   # [1, H, W, sum(size), rot, 7]
+
+    def get_cls_layer_loss(self):
+        cls_preds = self.forward_ret_dict['cls_preds']
+        labels = self.forward_ret_dict['box_cls_labels']
+        batch_size = int(cls_preds.shape[0])
+        cared = labels >= 0
+        positives = labels > 0
+        negatives = labels == 0
+        cls_weights = (negatives * 1.0 + 1.0 * positives).float()
+        if self.num_class == 1:
+            labels = torch.where(positives, torch.ones_like(labels), labels)
+        pos_normalizer = positives.sum(1, keepdim=True).float()
+        cls_weights = cls_weights / torch.clamp(pos_normalizer, min=1.0)
+        cls_targets = (labels * cared.type_as(labels)).long()
+        one_hot = torch.zeros(*cls_targets.shape, self.num_class + 1, dtype=cls_preds.dtype, device=cls_targets.device)
+        one_hot.scatter_(-1, cls_targets.unsqueeze(-1), 1.0)
+        cls_preds = cls_preds.view(batch_size, -1, self.num_class)
+        loss_src = self.cls_loss_func(cls_preds, one_hot[..., 1:], weights=cls_weights)
+        cls_loss = loss_src.sum() / batch_size * self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['cls_weight']
+        return cls_loss, {'rpn_loss_cls': cls_loss.detach()}
+
+    @staticmethod
+    def add_sin_difference(boxes1, boxes2, dim=6):
+        assert dim != -1
+        s1, c1 = torch.sin(boxes1[..., dim:dim + 1]), torch.cos(boxes1[..., dim:dim + 1])
+        s2, c2 = torch.sin(boxes2[..., dim:dim + 1]), torch.cos(boxes2[..., dim:dim + 1])
+        b1 = torch.cat([boxes1[..., :dim], s1 * c2, boxes1[..., dim + 1:]], dim=-1)
+        b2 = torch.cat([boxes2[..., :dim], c1 * s2, boxes2[..., dim + 1:]], dim=-1)
+        return b1, b2
+
+    @staticmethod
+    def get_direction_target(anchors, reg_targets, one_hot=True, dir_offset=0, num_bins=2):
+        batch_size = reg_targets.shape[0]
+        anchors = anchors.view(batch_size, -1, anchors.shape[-1])
+        rot_gt = reg_targets[..., 6] + anchors[..., 6]
+        offset_rot = common_utils.limit_period(rot_gt - dir_offset, 0, 2 * np.pi)
+        dir_cls = torch.floor(offset_rot / (2 * np.pi / num_bins)).long().clamp(min=0, max=num_bins - 1)
+        if one_hot:
+            t = torch.zeros(*dir_cls.shape, num_bins, dtype=anchors.dtype, device=dir_cls.device)
+            t.scatter_(-1, dir_cls.unsqueeze(-1), 1.0)
+            return t
+        return dir_cls
+
+    def get_box_reg_layer_loss(self):
+        box_preds = self.forward_ret_dict['box_preds']
+        dir_preds = self.forward_ret_dict.get('dir_cls_preds', None)
+        reg_targets = self.forward_ret_dict['box_reg_targets']
+        labels = self.forward_ret_dict['box_cls_labels']
+        batch_size = int(box_preds.shape[0])
+        positives = labels > 0
+        reg_weights = positives.float()
+        reg_weights = reg_weights / torch.clamp(positives.sum(1, keepdim=True).float(), min=1.0)
+        anchors = self._flat_anchors()
+        anchors = anchors.view(1, -1, anchors.shape[-1]).repeat(batch_size, 1, 1)
+        box_preds = box_preds.view(batch_size, -1, box_preds.shape[-1] // self.num_anchors_per_location)
+        preds_sin, targets_sin = self.add_sin_difference(box_preds, reg_targets)
+        loc_loss = self.reg_loss_func(preds_sin, targets_sin, weights=reg_weights).sum() / batch_size
+        loc_loss = loc_loss * self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['loc_weight']
+        box_loss = loc_loss
+        tb_dict = {'rpn_loss_loc': loc_loss.detach()}
+        if dir_preds is not None:
+            dir_targets = self.get_direction_target(anchors, reg_targets, dir_offset=self.model_cfg.DIR_OFFSET,
+                                                    num_bins=self.model_cfg.NUM_DIR_BINS)
+            dir_logits = dir_preds.view(batch_size, -1, self.model_cfg.NUM_DIR_BINS)
+            weights = positives.type_as(dir_logits)
+            weights = weights / torch.clamp(weights.sum(-1, keepdim=True), min=1.0)
+            dir_loss = self.dir_loss_func(dir_logits, dir_targets, weights=weights).sum() / batch_size
+            dir_loss = dir_loss * self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS['dir_weight']
+            box_loss = box_loss + dir_loss
+            tb_dict['rpn_loss_dir'] = dir_loss.detach()
+        return box_loss, tb_dict
+
+    def get_loss(self):
+        cls_loss, tb_dict = self.get_cls_layer_loss()
+        box_loss, tb_box = self.get_box_reg_layer_loss()
+        tb_dict.update(tb_box)
+        rpn_loss = cls_loss + box_loss
+        tb_dict['rpn_loss'] = rpn_loss.detach()
+        return rpn_loss, tb_dict
+
+    def generate_predicted_boxes(self, batch_size, cls_preds, box_preds, dir_cls_preds=None):
+        """cls_preds (N,H,W,C1), box_preds (N,H,W,C2), dir (N,H,W,C3) -> (B, A, n_cls) logits, (B, A, 7) boxes."""
+        anchors = self._flat_anchors()
+        num_anchors = anchors.view(-1, anchors.shape[-1]).shape[0]
+        batch_anchors = anchors.view(1, -1, anchors.shape[-1]).repeat(batch_size, 1, 1)
+        batch_cls_preds = cls_preds.view(batch_size, num_anchors, -1).float()
+        batch_box_preds = self.box_coder.decode_torch(box_preds.view(batch_size, num_anchors, -1), batch_anchors)
+        if dir_cls_preds is not None:
+            dir_offset = self.model_cfg.DIR_OFFSET
+            dir_limit_offset = self.model_cfg.DIR_LIMIT_OFFSET
+            dir_labels = torch.max(dir_cls_preds.view(batch_size, num_anchors, -1), dim=-1)[1]
+            period = 2 * np.pi / self.model_cfg.NUM_DIR_BINS
+            dir_rot = common_utils.limit_period(batch_box_preds[..., 6] - dir_offset, dir_limit_offset, period)
+            heading = dir_rot + dir_offset + period * dir_labels.to(batch_box_preds.dtype)
+            batch_box_preds = torch.cat([batch_box_preds[..., :6], heading.unsqueeze(-1), batch_box_preds[..., 7:]], -1)
+        return batch_cls_preds, batch_box_preds
+
+    def forward(self, **kwargs):
+        raise NotImplementedError

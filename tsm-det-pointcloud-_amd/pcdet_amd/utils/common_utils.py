@@ -1,0 +1,75 @@
+"""Small helpers the hot path needs (subset of the reference's pcdet/utils/common_utils.py)."""
+import logging
+import os
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def limit_period(val, offset=0.5, period=np.pi):
+    """val - floor(val/period + offset) * period  (reference common_utils.py:27-30)."""
+    is_np = isinstance(val, np.ndarray)
+    t = torch.from_numpy(val).float() if is_np else val
+    out = t - torch.floor(t / period + offset) * period
+    return out.numpy() if is_np else out
+
+
+def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_range):
+    """(z,y,x) voxel indices -> metric xyz centres (reference common_utils.py:73-89)."""
+    assert voxel_coords.shape[1] == 3
+    xyz = voxel_coords[:, [2, 1, 0]].float()
+    vs = torch.tensor(voxel_size, device=xyz.device).float() * downsample_times
+    lo = torch.tensor(point_cloud_range[0:3], device=xyz.device).float()
+    return (xyz + 0.5) * vs + lo
+
+
+def mask_points_by_range(points, limit_range):
+    """reference common_utils.py:66-70 (upper bound hi - 0.0002)."""
+    return (points[:, 0] >= limit_range[0]) & (points[:, 0] <= (limit_range[3] - 0.0002)) \
+        & (points[:, 1] >= limit_range[1]) & (points[:, 1] <= (limit_range[4] - 0.0002)) \
+        & (points[:, 2] >= limit_range[2]) & (points[:, 2] <= (limit_range[5] - 0.0002))
+
+
+def create_logger(log_file=None, rank=0, log_level=logging.INFO):
+    logger = logging.getLogger("pcdet_amd")
+    logger.setLevel(log_level if rank == 0 else "ERROR")
+    if not logger.handlers:
+        fmt = logging.Formatter("%(asctime)s  %(levelname)5s  %(message)s")
+        console = logging.StreamHandler()
+        console.setFormatter(fmt)
+        logger.addHandler(console)
+        if log_file is not None:
+            fh = logging.FileHandler(filename=log_file)
+            fh.setFormatter(fmt)
+            logger.addHandler(fh)
+    logger.propagate = False
+    return logger
+
+
+def set_random_seed(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def get_dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_dist_pytorch(tcp_port=None, local_rank=None, backend="nccl"):
+    """One process per GPU; backend 'nccl' IS RCCL on PyTorch-ROCm (reference common_utils.py:184-199).
+    Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun)."""
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if backend == "nccl":
+        num_gpus = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % max(num_gpus, 1))
+    if tcp_port is not None and "MASTER_PORT" not in os.environ:
+        os.environ["MASTER_PORT"] = str(tcp_port)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend=backend)
+    return dist.get_world_size(), dist.get_rank()

@@ -1,0 +1,78 @@
+"""autograd.Function wrappers: every forward AND backward below is a libspx HIP kernel (via spx.ops).
+
+Replaces the autograd behaviour of spconv.pytorch convolutions / .dense() that the reference triggers with
+loss.backward() (tools/train_utils/train_utils.py:53).
+"""
+import torch
+
+from . import ops
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """out = gather(src, pair_f) (*) W   — one sparse conv application.
+
+    pair_f/ld_f/n_dst : table used in the forward direction (rows of the result)
+    pair_b/ld_b/flip_b: table used for dgrad (rows of the source); flip_b reads the forward table at K-1-k
+    """
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias, pair_f, ld_f, n_dst, pair_b, ld_b, flip_b, scale, shift, relu):
+        cout, cin = weight.shape[0], weight.shape[-1]
+        kvol = weight.numel() // (cout * cin)
+        wp = ops.pack_weight(weight, 0)
+        sh = shift if shift is not None else bias
+        out = ops.conv_gemm(feats, wp, cout, kvol, pair_f, ld_f, n_dst, flip_k=False, scale=scale, shift=sh, relu=relu)
+        ctx.save_for_backward(feats, weight)
+        ctx.tables = (pair_f, ld_f, n_dst, pair_b, ld_b, flip_b)
+        ctx.has_bias = bias is not None
+        ctx.fused = scale is not None or shift is not None or relu
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.fused:
+            raise RuntimeError("fused scale/shift/relu epilogue is inference-only")
+        feats, weight = ctx.saved_tensors
+        pair_f, ld_f, n_dst, pair_b, ld_b, flip_b = ctx.tables
+        cout, cin = weight.shape[0], weight.shape[-1]
+        kvol = weight.numel() // (cout * cin)
+        dout = dout.contiguous()
+        dfe = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = ops.pack_weight(weight, 1)
+            dfe = ops.conv_gemm(dout, wt, cin, kvol, pair_b, ld_b, feats.shape[0], flip_k=flip_b)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dout.sum(0)
+        return dfe, dw, db, None, None, None, None, None, None, None, None, None
+
+
+def sparse_conv(feats, weight, bias, rb, inverse=False, scale=None, shift=None, relu=False):
+    """Apply rulebook `rb` (spx.ops.Rulebook).  inverse=True swaps the roles of the two tables
+    (SparseInverseConv3d: outputs are the strided conv's inputs)."""
+    if not inverse:
+        if rb.subm:
+            return _SparseConvFn.apply(feats, weight, bias, rb.pair, rb.ld, rb.n_out, rb.pair, rb.ld, True, scale,
+                                       shift, relu)
+        return _SparseConvFn.apply(feats, weight, bias, rb.pair, rb.ld, rb.n_out, rb.pair_bwd, rb.pair_bwd.shape[1],
+                                   False, scale, shift, relu)
+    assert not rb.subm and rb.pair_bwd is not None
+    return _SparseConvFn.apply(feats, weight, bias, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in, rb.pair, rb.ld, False,
+                               scale, shift, relu)
+
+
+class _DenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, indices, batch_size, spatial_shape, channels_last):
+        ctx.args = (indices, batch_size, list(spatial_shape), channels_last)
+        return ops.densify(feats, indices, batch_size, spatial_shape, channels_last)
+
+    @staticmethod
+    def backward(ctx, ddense):
+        indices, batch_size, spatial_shape, channels_last = ctx.args
+        return ops.densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last), None, None, None, None
+
+
+def dense(feats, indices, batch_size, spatial_shape, channels_last=False):
+    return _DenseFn.apply(feats, indices, batch_size, spatial_shape, channels_last)

@@ -1,0 +1,210 @@
+"""spconv.pytorch-compatible module surface (SURVEY.md §8b boundary B2) on top of libspx.
+
+Names, constructor arguments, parameter names/shapes and indice_key caching follow what the reference uses:
+  spconv.SparseSequential / SparseModule  — pcdet/models/backbones_3d/spconv_backbone.py:24-33,38,85-125
+  spconv.SubMConv3d / SparseConv3d / SparseInverseConv3d — spconv_backbone.py:13-19,46-53,86,121-122
+  spconv.conv.SparseConvolution (isinstance target of find_all_spconv_keys) — pcdet/utils/spconv_utils.py:19
+  weight [Cout, kz, ky, kx, Cin], optional bias [Cout] — detector3d_template.py:547-562
+"""
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import functional as F_
+from . import ops
+from .tensor import SparseConvTensor
+
+
+class SparseModule(nn.Module):
+    """Marker base class: modules that take and return a SparseConvTensor."""
+    pass
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+def is_sparse_conv(module):
+    return isinstance(module, SparseConvolution)
+
+
+class SparseSequential(SparseModule):
+    """Sequential container that routes SparseConvTensors to sparse modules and `.features` to dense ones
+    (BatchNorm1d, ReLU, ...), as the reference relies on at spconv_backbone.py:24-33."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError("index {} is out of range".format(idx))
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for module in self._modules.values():
+            if is_spconv_module(module):
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input = input.replace_feature(module(input.features))
+            else:
+                input = module(input)
+        return input
+
+
+def _triple(v, ndim=3):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == ndim
+        return [int(x) for x in v]
+    return [int(v)] * ndim
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 algo=None, fp32_accum=None, name=None, **_unused):
+        super().__init__()
+        if ndim != 3:
+            raise NotImplementedError("libspx implements 3-D sparse convolution only (the reference uses no other)")
+        if groups != 1:
+            raise NotImplementedError("groups != 1 is not used by the reference and not implemented")
+        if transposed:
+            raise NotImplementedError("SparseConvTranspose3d is not used by the reference and not implemented")
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _triple(kernel_size)
+        self.stride = _triple(stride)
+        self.padding = _triple(padding)
+        self.dilation = _triple(dilation)
+        self.output_padding = _triple(output_padding)
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        self.subm, self.inverse, self.transposed = subm, inverse, transposed
+        self.groups = groups
+        self.indice_key = indice_key
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # same fan-in (K * Cin) and bound as torch's conv default (kaiming_uniform(a=sqrt(5)))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+            bound = 1.0 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        s = "{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}, padding={padding}"
+        if self.subm:
+            s += ", subm"
+        if self.inverse:
+            s += ", inverse"
+        if self.indice_key is not None:
+            s += ", indice_key={indice_key}"
+        return s.format(**self.__dict__)
+
+    def _rulebook(self, x):
+        """Find (indice_key cache) or build the rulebook; returns (rulebook, out_indices, out_shape)."""
+        cached = x.find_indice_pair(self.indice_key)
+        if self.inverse:
+            if cached is None:
+                raise ValueError("SparseInverseConv3d needs the rulebook of the conv with indice_key=%r"
+                                 % self.indice_key)
+            if cached.n_out != x.indices.shape[0]:
+                raise ValueError("inverse conv input does not match the cached forward conv output")
+            return cached
+        if cached is not None:
+            if self.subm and (cached.n_in != x.indices.shape[0] or cached.ksize != self.kernel_size):
+                raise ValueError("indice_key %r was built for a different tensor / kernel" % self.indice_key)
+            return cached
+        if self.subm:
+            rb = ops.subm_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation)
+        else:
+            rb = ops.conv_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
+                                   self.padding, self.dilation)
+        if self.indice_key is not None:
+            x.indice_dict[self.indice_key] = rb
+        return rb
+
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        feats = x.features
+        if feats.shape[1] != self.in_channels:
+            raise ValueError("channel size mismatch: got %d, conv expects %d" % (feats.shape[1], self.in_channels))
+        rb = self._rulebook(x)
+        out_feats = F_.sparse_conv(feats, self.weight, self.bias, rb, inverse=self.inverse)
+        if self.inverse:
+            out = SparseConvTensor(out_feats, self._inverse_indices(x, rb), rb.in_shape,
+                                   x.batch_size, x.grid, x.voxel_num, x.indice_dict, x.benchmark)
+        elif self.subm:
+            out = x.replace_feature(out_feats)
+        else:
+            out = SparseConvTensor(out_feats, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.voxel_num,
+                                   x.indice_dict, x.benchmark)
+        return out
+
+    @staticmethod
+    def _inverse_indices(x, rb):
+        idx = getattr(rb, "in_indices", None)
+        if idx is None:
+            raise ValueError("rulebook does not carry the forward conv's input indices")
+        return idx
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None, **kw):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, subm=True,
+                         indice_key=indice_key, algo=algo, **kw)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None, **kw):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key, algo=algo, **kw)
+
+    def _rulebook(self, x):
+        rb = super()._rulebook(x)
+        if getattr(rb, "in_indices", None) is None:
+            rb.in_indices = x.indices  # kept for SparseInverseConv3d with the same indice_key
+        return rb
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True, algo=None, fp32_accum=None,
+                 name=None, **kw):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key,
+                         algo=algo, **kw)
+
+
+class ToDense(SparseModule):
+    def forward(self, x):
+        return x.dense()
