@@ -1,0 +1,357 @@
+"""bench.py — headline benchmark: point-cloud frames/s (fwd+bwd+optimizer step) of the SECOND detector on the
+VoxelBackBone8x hot path, KITTI-shaped synthetic frames (BASELINE.json configs[1]: ~20k points, 16k active voxels
+per frame, batch 4 per GPU), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A step = PointToVoxel scatter + MeanVFE -> VoxelBackBone8x (12 sparse convs, 8 rulebooks) -> BEV collapse ->
+BaseBEVBackbone -> AnchorHeadSingle -> target assignment + losses -> backward -> grad clip -> AdamW(one-cycle) step,
+on points already resident in HBM.  Frames are sharded over ranks (weak scaling); the only collective is DDP's
+gradient all-reduce (RCCL over xGMI).  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline      for the dominant hand-written kernel, from HIP events recorded around every launch of it on the
+                launch stream during extra instrumented steps of the same workload (the timed region itself runs
+                un-instrumented), algorithmic FLOPs/bytes per SURVEY.md §8(d);
+  cpu_baseline  the CPU oracle (numpy per-offset gather-GEMM-scatter restatement of spconv's CPU algorithm, all
+                host cores, + torch-CPU dense tail) timed on a bounded sample: one frame of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "tsm-det-pointcloud-_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK = 8.0e12      # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
+MFMA_F32_PEAK = 157.3e12  # FLOP/s (dense fp32 MFMA, v_mfma_f32_16x16x4_f32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cfg", type=int, default=2, help="synthetic config id (BASELINE.md §4); 2 = KITTI batch 4")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU (default: the config's)")
+    ap.add_argument("--mode", default="train", choices=["train", "fwd"])
+    ap.add_argument("--dense-dtype", default="f32", choices=["f32", "bf16", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    return ap.parse_args()
+
+
+def build(cfg_id, device, dense_dtype):
+    from pcdet_amd.config import AttrDict, cfg_from_yaml_file
+    from pcdet_amd.datasets import SyntheticDataset, synthetic
+    from pcdet_amd.models import build_network
+    from tools.train_utils.optimization import build_optimizer, build_scheduler
+    name = synthetic.CONFIGS[cfg_id]["geom"]["name"]
+    ymodel = "waymo_models/second.yaml" if name == "waymo" else "kitti_models/second.yaml"
+    cfg = cfg_from_yaml_file(os.path.join(PKG, "tools", "cfgs", ymodel), AttrDict())
+    ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True, cfg_id=cfg_id)
+    cfg.MODEL.VFE.VOXELIZE.MAX_NUMBER_OF_VOXELS = ds.max_voxels
+    torch.manual_seed(0)
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+    model.to(device)
+    if dense_dtype != "f32" or device.type == "cuda":
+        model.backbone_2d.to(memory_format=torch.channels_last)
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    sched, _ = build_scheduler(optimizer, 1000, 80, -1, cfg.OPTIMIZATION)
+    return cfg, ds, model, optimizer, sched
+
+
+def make_batches(ds, cfg_id, batch, rank, device, n=2):
+    from pcdet_amd.datasets import synthetic
+    out = []
+    for j in range(n):
+        b = synthetic.make_batch(cfg_id, batch, start_frame=(rank * n + j) * batch)
+        out.append({"points": torch.from_numpy(b["points"]).to(device), "gt_boxes": torch.from_numpy(b["gt_boxes"]).to(device),
+                    "batch_size": batch})
+    return out
+
+
+class Step(object):
+    def __init__(self, model, optimizer, sched, clip, mode, dense_dtype):
+        self.model, self.opt, self.sched, self.clip, self.mode = model, optimizer, sched, clip, mode
+        self.dense_dtype = {"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}[dense_dtype]
+        self.it = 0
+        core = model.module if hasattr(model, "module") else model
+        if self.dense_dtype is not None:
+            fwd = core.backbone_2d.forward
+            dt = self.dense_dtype
+
+            def amp_forward(data_dict):
+                with torch.autocast("cuda", dtype=dt):
+                    return fwd(data_dict)
+            core.backbone_2d.forward = amp_forward
+
+    def __call__(self, batch):
+        bd = dict(batch)
+        if self.mode == "fwd":
+            with torch.no_grad():
+                for m in (self.model.module if hasattr(self.model, "module") else self.model).module_list:
+                    bd = m(bd)
+            return bd["batch_box_preds"]
+        self.sched.step(self.it)
+        self.opt.zero_grad(set_to_none=True)
+        ret, _tb, _ = self.model(bd)
+        loss = ret["loss"].mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip, foreach=True)
+        self.opt.step()
+        self.it += 1
+        return loss
+
+
+# ------------------------------------------------------------------------------------------ instrumentation
+
+class KernelTimer(object):
+    """HIP events (torch.cuda.Event on the launch stream = torch's current stream, which is the stream every spx
+    kernel is enqueued on) around each spx.ops call; algorithmic FLOPs / bytes per SURVEY.md §8(d)."""
+
+    def __init__(self):
+        self.rec = []      # (family, flops, bytes, ev0, ev1)
+        self._saved = {}
+        self._pairs = {}   # id(pair tensor) -> number of valid pairs P
+
+    def _P(self, pair, n):
+        key = (pair.data_ptr(), int(n))
+        if key not in self._pairs:
+            self._pairs[key] = int((pair[:, :n] >= 0).sum().item())
+        return self._pairs[key]
+
+    def _timed(self, family, flops, nbytes, fn, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a, **k)
+        e1.record()
+        self.rec.append((family, flops, nbytes, e0, e1))
+        return out
+
+    def install(self):
+        from spx import ops
+        t = self
+        names = ["conv_gemm", "conv_wgrad", "subm_rulebook", "conv_rulebook", "voxelize", "densify", "densify_bwd",
+                 "pack_weight"]
+        self._saved = {n: getattr(ops, n) for n in names}
+        sv = self._saved
+
+        def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False):
+            cs = src.shape[1]
+            P = t._P(pair, n_dst)
+            flops = 2.0 * P * cs * c_dst
+            nbytes = 4.0 * (src.shape[0] * cs + n_dst * c_dst + kvol * cs * c_dst + kvol * n_dst)
+            fam = "conv_gemm[mfma]" if (cs % 16 == 0 and c_dst % 16 == 0) else "conv_gemm[valu]"
+            return t._timed(fam, flops, nbytes, sv["conv_gemm"], src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k,
+                            scale, shift, relu)
+
+        def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
+            cout, cin = wshape[0], wshape[-1]
+            K = int(np.prod(wshape[1:-1]))
+            P = t._P(pair, n_out)
+            flops = 2.0 * P * cin * cout
+            nbytes = 4.0 * (feat_in.shape[0] * cin + n_out * cout + K * n_out + K * cin * cout)
+            return t._timed("conv_wgrad", flops, nbytes, sv["conv_wgrad"], feat_in, dout, pair, ld, n_out, wshape)
+
+        def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False):
+            n = indices.shape[0]
+            K = int(np.prod(ksize))
+            return t._timed("subm_rulebook", 0.0, n * 16.0 + K * n * 4.0, sv["subm_rulebook"], indices, batch_size,
+                            spatial_shape, ksize, dilation, want_cnt)
+
+        def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1),
+                          want_cnt=False):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rb = sv["conv_rulebook"](indices, batch_size, spatial_shape, ksize, stride, padding, dilation, want_cnt)
+            e1.record()
+            n, K = indices.shape[0], int(np.prod(ksize))
+            t.rec.append(("conv_rulebook", 0.0, n * 16.0 + K * rb.n_out * 4.0 + K * n * 4.0 + rb.n_out * 16.0, e0, e1))
+            return rb
+
+        def voxelize(points, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = sv["voxelize"](points, *a, **k)
+            e1.record()
+            c = out["mean"].shape[1] if out["mean"] is not None else 4
+            t.rec.append(("voxelize+meanvfe", 0.0, 4.0 * points.shape[0] * c + 4.0 * out["num_voxels"] * (c + 4), e0, e1))
+            return out
+
+        def densify(features, indices, batch_size, spatial_shape, channels_last=False):
+            n, c = features.shape
+            cells = batch_size * int(np.prod(spatial_shape))
+            return t._timed("densify(+memset)", 0.0, 4.0 * (n * c + c * cells), sv["densify"], features, indices,
+                            batch_size, spatial_shape, channels_last)
+
+        def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False):
+            n, c = indices.shape[0], ddense.shape[1]
+            return t._timed("densify_bwd", 0.0, 8.0 * n * c, sv["densify_bwd"], ddense, indices, batch_size,
+                            spatial_shape, channels_last)
+
+        def pack_weight(weight, mode):
+            return t._timed("pack_weight", 0.0, 8.0 * weight.numel(), sv["pack_weight"], weight, mode)
+
+        for n, f in dict(conv_gemm=conv_gemm, conv_wgrad=conv_wgrad, subm_rulebook=subm_rulebook,
+                         conv_rulebook=conv_rulebook, voxelize=voxelize, densify=densify, densify_bwd=densify_bwd,
+                         pack_weight=pack_weight).items():
+            setattr(ops, n, f)
+
+    def uninstall(self):
+        from spx import ops
+        for n, f in self._saved.items():
+            setattr(ops, n, f)
+
+    def summary(self, nsteps):
+        torch.cuda.synchronize()
+        fam = {}
+        for name, fl, by, e0, e1 in self.rec:
+            d = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, roof_hbm=0.0, roof_mfma=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+            d["roof_hbm"] += by / HBM_PEAK
+            d["roof_mfma"] += fl / MFMA_F32_PEAK
+        for d in fam.values():
+            d["ms_per_step"] = d["ms"] / nsteps
+            d["launches_per_step"] = d["launches"] / nsteps
+        return fam
+
+
+def roofline_of(fam):
+    """Dominant hand-written kernel family by time -> the roofline object of the contract."""
+    name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    t = d["ms"] * 1e-3
+    if d["roof_mfma"] >= d["roof_hbm"]:
+        ach, peak, unit, bound = d["flops"] / t / 1e12, MFMA_F32_PEAK / 1e12, "TFLOP/s", "mfma"
+    else:
+        ach, peak, unit, bound = d["bytes"] / t / 1e9, HBM_PEAK / 1e9, "GB/s", "hbm"
+    return {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+            "frac": round(ach / peak, 4), "traffic": None,
+            "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches_per_step"],
+            "algorithmic_flops_per_launch": d["flops"] / d["launches"],
+            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"]}
+
+
+def cpu_baseline(cfg_id, mode):
+    """One frame of the same workload on the host: oracle sparse ops + torch-CPU dense tail, all cores."""
+    from oracle.cpu_backend import use_oracle_backend
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    dev = torch.device("cpu")
+    _cfg, ds, model, opt, sched = build(cfg_id, dev, "f32")
+    batch = make_batches(ds, cfg_id, 1, 0, dev, n=1)[0]
+    step = Step(model, opt, sched, 10.0, mode, "f32")
+    model.train(mode == "train")
+    with use_oracle_backend():
+        t0 = time.time()
+        step(batch)
+        dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 frame of cfg %d (%s), full detector %s, oracle numpy gather-GEMM-scatter sparse ops + torch-CPU "
+                      "dense tail, %.1f s" % (cfg_id, "KITTI-shaped 20k pts / 16k voxels" if cfg_id == 2 else "see BASELINE.md",
+                                              "fwd+bwd+step" if mode == "train" else "fwd", dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the sparse hot path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    from pcdet_amd.datasets import synthetic
+    batch = args.batch or synthetic.CONFIGS[args.cfg]["batch"]
+    cfg, ds, model, optimizer, sched = build(args.cfg, device, args.dense_dtype)
+    model.train(args.mode == "train")
+    if world > 1 and args.mode == "train":
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=32,
+                                                          gradient_as_bucket_view=True, broadcast_buffers=False)
+    batches = make_batches(ds, args.cfg, batch, rank, device)
+    step = Step(model, optimizer, sched, cfg.OPTIMIZATION.GRAD_NORM_CLIP, args.mode, args.dense_dtype)
+
+    for i in range(args.warmup):
+        step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    line = None
+    if rank == 0:
+        geom = synthetic.CONFIGS[args.cfg]
+        line = {
+            "metric": "point-cloud frames/sec (%s)" % ("fwd+bwd" if args.mode == "train" else "fwd"),
+            "value": round(world * batch * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dense_dtype == "f32" else "f32 sparse / %s dense tail (f32 accumulate, f32 head)"
+                     % args.dense_dtype,
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]: %s-shaped synthetic, %d pts / %d active voxels per frame, "
+                                   "full SECOND detector (VoxelBackBone8x) %s" %
+                                   (args.cfg - 1, geom["geom"]["name"].upper(), geom["n_points"], geom["n_active"],
+                                    "fwd+bwd+AdamW step" if args.mode == "train" else "forward"),
+                       "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": "dp%d" % world,
+                       "voxelize_on_gpu": True},
+        }
+    # ---- roofline: instrumented extra steps of the same workload (rank 0 prints; all ranks run them so DDP stays in step)
+    if not args.no_roofline:
+        kt = KernelTimer()
+        kt.install()
+        n_inst = 3
+        for i in range(n_inst):
+            step(batches[i % len(batches)])
+        fam = kt.summary(n_inst)
+        kt.uninstall()
+        if rank == 0:
+            line["roofline"] = roofline_of(fam)
+            line["kernels"] = {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"],
+                                   "GFLOP_per_step": round(v["flops"] / n_inst / 1e9, 3),
+                                   "MB_per_step": round(v["bytes"] / n_inst / 1e6, 3)} for k, v in fam.items()}
+            if args.breakdown:
+                for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+                    sys.stderr.write("%-22s %7.3f ms/step  %5.1f launches  %8.2f GFLOP  %8.2f MB  -> %6.2f TFLOP/s %7.1f GB/s\n"
+                                     % (k, v["ms_per_step"], v["launches_per_step"], v["flops"] / n_inst / 1e9,
+                                        v["bytes"] / n_inst / 1e6, v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                                        v["bytes"] / (v["ms"] * 1e-3) / 1e9))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.cfg, args.mode)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,176 @@
+"""Whole-backbone / whole-detector parity: the HIP path (spx.ops -> libspx.so) against the SAME module definitions
+run on the host through the oracle backend (oracle/cpu_backend.py), forward and backward.
+
+Tolerances (north_star): voxel indices bit-exact; per-layer sparse features 1e-4 relative to the layer's max|x|
+(fp32, 12 chained convs + train-mode BatchNorm whose batch statistics amplify round-off); boxes within 1e-3."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(cfg_id=0, seed=0):
+    from pcdet_amd.config import AttrDict, cfg_from_yaml_file
+    from pcdet_amd.datasets import SyntheticDataset
+    from pcdet_amd.models import build_network
+    cfg = cfg_from_yaml_file(os.path.join(ROOT, "tsm-det-pointcloud-_amd/tools/cfgs/kitti_models/second.yaml"), AttrDict())
+    ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, True, cfg_id=cfg_id)
+    torch.manual_seed(seed)
+    model = build_network(cfg.MODEL, 3, ds)
+    # non-trivial BN statistics so eval mode exercises them
+    g = torch.Generator().manual_seed(seed + 1)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    return cfg, ds, model
+
+
+def _batch(ds, n=2):
+    b = ds.collate_batch([ds[i] for i in range(n)])
+    return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def test_detector_eval_forward_parity():
+    from oracle.cpu_backend import use_oracle_backend
+    _cfg, ds, model = _build()
+    model.eval()
+    ref = copy.deepcopy(model)
+    bd_c = _batch(ds)
+    with torch.no_grad(), use_oracle_backend():
+        for m in ref.module_list:
+            bd_c = m(bd_c)
+    dev = torch.device("cuda:0")
+    model.to(dev)
+    bd_g = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in _batch(ds).items()}
+    with torch.no_grad():
+        for m in model.module_list:
+            bd_g = m(bd_g)
+    assert torch.equal(bd_g["voxel_coords"].cpu(), bd_c["voxel_coords"])
+    assert _rel(bd_g["voxel_features"], bd_c["voxel_features"]) < 1e-6
+    for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        tg, tc = bd_g["multi_scale_3d_features"][k], bd_c["multi_scale_3d_features"][k]
+        assert torch.equal(tg.indices.cpu(), tc.indices) and tg.spatial_shape == tc.spatial_shape
+        assert _rel(tg.features, tc.features) < 1e-4, k
+    eg, ec = bd_g["encoded_spconv_tensor"], bd_c["encoded_spconv_tensor"]
+    assert torch.equal(eg.indices.cpu(), ec.indices) and eg.spatial_shape == [2, 40, 32]
+    assert _rel(eg.features, ec.features) < 1e-4
+    assert _rel(bd_g["spatial_features"], bd_c["spatial_features"]) < 1e-4
+    assert _rel(bd_g["batch_cls_preds"], bd_c["batch_cls_preds"]) < 1e-4
+    # boxes within 1e-3 (absolute, metres / radians) of the reference semantics
+    assert float((bd_g["batch_box_preds"].cpu() - bd_c["batch_box_preds"]).abs().max()) < 1e-3
+
+
+def test_detector_train_step_parity():
+    """loss, every parameter gradient and the BN running statistics after one fwd+bwd."""
+    from oracle.cpu_backend import use_oracle_backend
+    _cfg, ds, model = _build(seed=3)
+    model.train()
+    ref = copy.deepcopy(model)
+    with use_oracle_backend():
+        ret_c, tb_c, _ = ref(_batch(ds))
+        ret_c["loss"].backward()
+    dev = torch.device("cuda:0")
+    model.to(dev)
+    bd = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in _batch(ds).items()}
+    ret_g, tb_g, _ = model(bd)
+    ret_g["loss"].backward()
+    assert abs(float(ret_g["loss"]) - float(ret_c["loss"])) < 1e-4 * abs(float(ret_c["loss"]))
+    for k in tb_c:
+        assert abs(float(tb_g[k]) - float(tb_c[k])) < 1e-4 * max(1.0, abs(float(tb_c[k]))), k
+    pg, pc = dict(model.named_parameters()), dict(ref.named_parameters())
+    # Train-mode BatchNorm + ReLU over 26 layers amplifies fp32 summation-ORDER differences: on the host alone, changing
+    # the BLAS thread count moves single gradients by ~3e-3 of their max (measured, tests/test_distributed.py).  So:
+    # per-parameter bound 2e-2, and a tight bound on the global relative L2 error.  Kernel-level gradients are held
+    # to 2e-5 in tests/test_gpu_kernels.py.
+    worst, num, den = ("", 0.0), 0.0, 0.0
+    for name, p in pc.items():
+        assert pg[name].grad is not None, name
+        r = _rel(pg[name].grad, p.grad)
+        if r > worst[1]:
+            worst = (name, r)
+        num += float((pg[name].grad.cpu().double() - p.grad.double()).pow(2).sum())
+        den += float(p.grad.double().pow(2).sum())
+    assert worst[1] < 2e-2, worst
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+    bg, bc = dict(model.named_buffers()), dict(ref.named_buffers())
+    for name in bc:
+        if name.endswith("running_mean") or name.endswith("running_var"):
+            assert _rel(bg[name], bc[name]) < 1e-4, name
+
+
+def test_inverse_conv_and_subm_k1():
+    """SparseInverseConv3d (rulebook roles swapped) and SubMConv3d k=1 (NEXT row f-2) against the oracle backend,
+    forward and backward."""
+    import spx
+    from oracle.cpu_backend import use_oracle_backend
+    g = torch.Generator().manual_seed(5)
+    shape, batch = [9, 24, 20], 2
+    cells = batch * shape[0] * shape[1] * shape[2]
+    lin = torch.randperm(cells, generator=g)[:600]
+    vol = shape[0] * shape[1] * shape[2]
+    idx = torch.stack([lin // vol, (lin % vol) // (shape[1] * shape[2]), (lin // shape[2]) % shape[1], lin % shape[2]],
+                      1).int()
+    feat = torch.randn(600, 16, generator=g)
+    net = spx.SparseSequential(
+        spx.SubMConv3d(16, 16, 1, bias=True, indice_key="k1"),
+        spx.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False, indice_key="down"),
+        spx.SubMConv3d(32, 32, 3, bias=True, indice_key="s2"),
+        spx.SparseInverseConv3d(32, 16, 3, indice_key="down", bias=False),
+    )
+    ref = copy.deepcopy(net)
+
+    def run(m, f, i):
+        f = f.clone().requires_grad_(True)
+        out = m(spx.SparseConvTensor(f, i, shape, batch))
+        (out.features * torch.linspace(-1, 1, out.features.numel(), device=f.device).view_as(out.features)).sum().backward()
+        return out, f.grad
+
+    with use_oracle_backend():
+        oc, gc = run(ref, feat, idx)
+    dev = torch.device("cuda:0")
+    net.to(dev)
+    og, gg = run(net, feat.to(dev), idx.to(dev))
+    assert torch.equal(og.indices.cpu(), idx) and og.spatial_shape == shape
+    assert _rel(og.features, oc.features) < 1e-5
+    assert _rel(gg, gc) < 1e-5
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert _rel(p.grad, q.grad) < 1e-4, n
+
+
+def test_kitti_full_size_forward_properties():
+    """BASELINE cfg 2 (4 x 16k voxels, full KITTI grid): stage shapes, finite outputs, idempotent re-run."""
+    from pcdet_amd.datasets import synthetic
+    _cfg, ds, model = _build(cfg_id=2)
+    dev = torch.device("cuda:0")
+    model.to(dev).eval()
+    b = synthetic.make_batch(2, 4)
+    bd = {"points": torch.from_numpy(b["points"]).to(dev), "gt_boxes": torch.from_numpy(b["gt_boxes"]).to(dev),
+          "batch_size": 4}
+    with torch.no_grad():
+        out = dict(bd)
+        for m in model.module_list:
+            out = m(out)
+        out2 = dict(bd)
+        for m in model.module_list[:2]:
+            out2 = m(out2)
+    assert out["voxel_coords"].shape[0] == 4 * 16000
+    shapes = [out["multi_scale_3d_features"][k].spatial_shape for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4")]
+    assert shapes == [[41, 1600, 1408], [21, 800, 704], [11, 400, 352], [5, 200, 176]]
+    assert out["encoded_spconv_tensor"].spatial_shape == [2, 200, 176]
+    assert list(out["spatial_features"].shape) == [4, 256, 200, 176]
+    assert list(out["batch_box_preds"].shape) == [4, 211200, 7] and list(out["batch_cls_preds"].shape) == [4, 211200, 3]
+    assert bool(torch.isfinite(out["batch_box_preds"]).all()) and bool(torch.isfinite(out["batch_cls_preds"]).all())
+    assert torch.equal(out["encoded_spconv_tensor"].features, out2["encoded_spconv_tensor"].features)  # deterministic

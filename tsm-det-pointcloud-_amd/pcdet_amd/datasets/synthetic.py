@@ -21,8 +21,14 @@ WAYMO = dict(name="waymo", point_cloud_range=[-75.2, -75.2, -2.0, 75.2, 75.2, 4.
              num_point_features=5, max_points_per_voxel=5, max_voxels=dict(train=150000, test=150000),
              sensor_xy=(0.0, 0.0), class_names=["Vehicle", "Pedestrian", "Cyclist"])
 
+#: reduced KITTI-like geometry for fast CPU / parity tests (same voxel size, 12.8 m x 16 m range -> BEV 32 x 40)
+MINI = dict(name="kitti", point_cloud_range=[0.0, -8.0, -3.0, 12.8, 8.0, 1.0], voxel_size=[0.05, 0.05, 0.1],
+            num_point_features=4, max_points_per_voxel=5, max_voxels=dict(train=16000, test=40000),
+            sensor_xy=(0.0, 0.0), class_names=["Car", "Pedestrian", "Cyclist"])
+
 #: BASELINE.json configs[0..4] -> (geometry, points/frame, active voxels/frame, batch)
 CONFIGS = {
+    0: dict(geom=MINI, n_points=4000, n_active=1500, batch=2, n_obj=4),
     1: dict(geom=KITTI, n_points=16384, n_active=5000, batch=1, crop=True),
     2: dict(geom=KITTI, n_points=20000, n_active=16000, batch=4),
     3: dict(geom=WAYMO, n_points=180000, n_active=80000, batch=2),
@@ -69,23 +75,25 @@ def make_frame(cfg_id, frame_idx=0, with_boxes=True):
     keys = np.empty((0,), np.int64)
     cand_xyz = []
     boxes = []
-    n_obj = 10 if geom["name"] == "kitti" else 40
+    n_obj = cfg.get("n_obj", 10 if geom["name"] == "kitti" else 40)
     # objects / walls first so they always survive de-duplication
     n_obj_vox = int(0.3 * n_active)
     per = max(n_obj_vox // (n_obj + 4), 8)
     ground_z = lo[2] + 0.45 * (hi[2] - lo[2]) if geom["name"] == "kitti" else lo[2] + 0.3 * (hi[2] - lo[2])
     ground_z = float(np.floor((ground_z - pr[2]) / vs[2]) * vs[2] + pr[2])
     for j in range(n_obj):
-        cx = rng.uniform(lo[0] + 5, hi[0] - 5)
-        cy = rng.uniform(lo[1] + 5, hi[1] - 5)
+        mrg = min(5.0, 0.25 * (hi[0] - lo[0]), 0.25 * (hi[1] - lo[1]))
+        cx = rng.uniform(lo[0] + mrg, hi[0] - mrg)
+        cy = rng.uniform(lo[1] + mrg, hi[1] - mrg)
         yaw = 0.0 if j % 2 == 0 else np.deg2rad(30.0)
         cls = 1 + (j % 3)
         dims = [(4.0, 1.8, 1.6), (0.8, 0.6, 1.73), (1.76, 0.6, 1.73)][cls - 1]
         cand_xyz.append(_box_surface(rng, cx, cy, ground_z, dims[0], dims[1], dims[2], yaw, vs, per * 6))
         boxes.append([cx, cy, ground_z + dims[2] / 2, dims[0], dims[1], dims[2], yaw, cls])
     for j in range(4):
-        cx = rng.uniform(lo[0] + 12, hi[0] - 12)
-        cy = rng.uniform(lo[1] + 12, hi[1] - 12)
+        mrg = min(12.0, 0.4 * (hi[0] - lo[0]), 0.4 * (hi[1] - lo[1]))
+        cx = rng.uniform(lo[0] + mrg, hi[0] - mrg)
+        cy = rng.uniform(lo[1] + mrg, hi[1] - mrg)
         cand_xyz.append(_box_surface(rng, cx, cy, ground_z, 20.0, 0.2, 3.0, rng.uniform(0, np.pi), vs, per * 12))
     obj = np.concatenate(cand_xyz, 0)
 
