@@ -1,0 +1,118 @@
+"""Per-layer microbenchmark of the sparse-conv kernels on the real rulebooks of a synthetic batch (dev tool).
+
+python tools/kbench.py [--cfg 2] [--batch 4] [--iters 20] [--what fwd,dgrad,wgrad,rulebook]
+Prints, per VoxelBackBone8x layer: rows, valid pairs, pairs/row, time, TFLOP/s (algorithmic 2*P*Cin*Cout), and the
+compulsory-bytes GB/s.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tsm-det-pointcloud-_amd")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import oracle as orc  # noqa: E402  (layer table only)
+from pcdet_amd.datasets import synthetic  # noqa: E402
+from spx import ops  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--what", default="fwd,dgrad,wgrad,rulebook")
+    ap.add_argument("--layers", default="")
+    args = ap.parse_args()
+    what = args.what.split(",")
+    dev = torch.device("cuda:0")
+    spec = synthetic.CONFIGS[args.cfg]
+    geom = spec["geom"]
+    batch = args.batch or spec["batch"]
+    b = synthetic.make_batch(args.cfg, batch)
+    pts = torch.from_numpy(b["points"]).to(dev)
+    mv = spec.get("max_voxels", geom["max_voxels"]["train"])
+    vox = ops.voxelize(pts, geom["point_cloud_range"], geom["voxel_size"], 5, mv, batch_size=batch, batch_col=0,
+                       xyz_col=1, feat_col=1, want_voxels=False)
+    if "rulebook" in what:
+        t = timeit(lambda: ops.voxelize(pts, geom["point_cloud_range"], geom["voxel_size"], 5, mv, batch_size=batch,
+                                        batch_col=0, xyz_col=1, feat_col=1, want_voxels=False), args.iters)
+        print("voxelize+meanvfe: %d pts -> %d voxels  %.1f us  (%.1f Mpts/s)" % (pts.shape[0], vox["num_voxels"], t * 1e6,
+                                                                               pts.shape[0] / t / 1e6))
+    gs = synthetic.grid_size_of(geom)
+    shape = [int(gs[2]) + 1, int(gs[1]), int(gs[0])]
+    idx = vox["coords"]
+    books = {}
+    g = torch.Generator().manual_seed(0)
+    tot = dict(fwd=0.0, dgrad=0.0, wgrad=0.0, rulebook=0.0, flops=0.0)
+    for name, cin, cout, ks, st, pd, ctype, key in orc.backbone8x_spec(geom["num_point_features"]):
+        if key not in books:
+            if ctype == "subm":
+                books[key] = ops.subm_rulebook(idx, batch, shape, ks)
+                fn = (lambda i=idx, s=list(shape), k=ks: ops.subm_rulebook(i, batch, s, k))
+            else:
+                books[key] = ops.conv_rulebook(idx, batch, shape, ks, st, pd)
+                fn = (lambda i=idx, s=list(shape), k=ks, a=st, p=pd: ops.conv_rulebook(i, batch, s, k, a, p))
+            if "rulebook" in what:
+                t = timeit(fn, args.iters)
+                tot["rulebook"] += t
+                print("  rulebook %-12s n_in %7d -> n_out %7d  %8.1f us  (%.1f Mvoxels/s)" % (
+                    key, idx.shape[0], books[key].n_out, t * 1e6, idx.shape[0] / t / 1e6))
+        rb = books[key]
+        if args.layers and name not in args.layers.split(","):
+            if ctype != "subm":
+                idx, shape = rb.out_indices, rb.out_shape
+            continue
+        K = rb.kvol
+        P = int((rb.pair[:, :rb.n_out] >= 0).sum().item())
+        x = torch.randn(rb.n_in, cin, generator=g).to(dev)
+        w = (torch.randn(cout, *ks, cin, generator=g) / np.sqrt(K * cin)).to(dev)
+        dout = torch.randn(rb.n_out, cout, generator=g).to(dev)
+        wp, wt = ops.pack_weight(w, 0), ops.pack_weight(w, 1)
+        flops = 2.0 * P * cin * cout
+        nbytes = 4.0 * (rb.n_in * cin + rb.n_out * cout + K * cin * cout + K * rb.n_out)
+        line = "%-12s %3d->%3d %-6s n_in %7d n_out %7d P %8d (%.1f/row)" % (name, cin, cout, ctype, rb.n_in, rb.n_out,
+                                                                              P, P / max(rb.n_out, 1))
+        if "fwd" in what:
+            t = timeit(lambda: ops.conv_gemm(x, wp, cout, K, rb.pair, rb.ld, rb.n_out), args.iters)
+            tot["fwd"] += t
+            tot["flops"] += flops
+            line += " | fwd %7.1f us %6.2f TF/s %6.0f GB/s" % (t * 1e6, flops / t / 1e12, nbytes / t / 1e9)
+        if "dgrad" in what and cin >= 16:
+            if rb.subm:
+                f = (lambda: ops.conv_gemm(dout, wt, cin, K, rb.pair, rb.ld, rb.n_in, flip_k=True))
+            else:
+                f = (lambda: ops.conv_gemm(dout, wt, cin, K, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in))
+            t = timeit(f, args.iters)
+            tot["dgrad"] += t
+            line += " | dgrad %7.1f us %6.2f TF/s" % (t * 1e6, flops / t / 1e12)
+        if "wgrad" in what:
+            t = timeit(lambda: ops.conv_wgrad(x, dout, rb.pair, rb.ld, rb.n_out, tuple(w.shape)), args.iters)
+            tot["wgrad"] += t
+            line += " | wgrad %7.1f us %6.2f TF/s" % (t * 1e6, flops / t / 1e12)
+        print(line)
+        if ctype != "subm":
+            idx, shape = rb.out_indices, rb.out_shape
+    print("TOTAL per batch of %d: fwd %.3f ms (%.2f TF/s)  dgrad %.3f ms  wgrad %.3f ms  rulebooks %.3f ms" % (
+        batch, tot["fwd"] * 1e3, tot["flops"] / max(tot["fwd"], 1e-9) / 1e12, tot["dgrad"] * 1e3, tot["wgrad"] * 1e3,
+        tot["rulebook"] * 1e3))
+
+
+if __name__ == "__main__":
+    main()
