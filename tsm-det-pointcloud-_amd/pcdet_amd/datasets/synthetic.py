@@ -3,7 +3,8 @@
 Real datasets are absent (no network); the reference's loaders (pcdet/datasets/kitti, waymo) are out of
 scope.  The generator draws the ACTIVE-VOXEL SET first so counts are pinned, then points inside those
 voxels:
-  1. ground sheet (70 %): (x, y) with radial density ~ 1/r around the sensor, z index = plane + {0,1};
+  1. ground sheet (70 %): scan arcs around the sensor whose radii grow geometrically (areal density ~ 1/r, returns
+     along a ring are voxel-contiguous like real scan lines), z index = plane + {0,1};
   2. object / wall sheets (30 %): surface voxels of axis-aligned and 30-degree-rotated boxes
      (4 x 1.8 x 1.6 m "cars") and 20 x 3 m walls; de-duplicated to exactly `n_active` voxels;
   3. per voxel 1 + Poisson(lambda) points uniform inside the cell (clipped to `n_points` total),
@@ -107,20 +108,51 @@ def make_frame(cfg_id, frame_idx=0, with_boxes=True):
     rng.shuffle(k_obj)
     k_obj = k_obj[:n_obj_vox]
     keys = k_obj
-    # ground sheet with ~1/r radial density, topped up until exactly n_active unique voxels
+    # ground sheet: LiDAR-like scan ARCS.  Ring radii grow geometrically (r_i = r0 * gamma^i), every ring is a
+    # voxel-contiguous arc, so the areal voxel density falls off ~ 1/r as the spec asks while neighbouring returns
+    # stay adjacent the way real scan lines do (isolated random voxels would dilate 8x at every strided conv).
     rmax = float(np.hypot(max(abs(lo[0] - sx), abs(hi[0] - sx)), max(abs(lo[1] - sy), abs(hi[1] - sy))))
-    while keys.size < n_active:
-        need = n_active - keys.size
-        m = int(need * 2.5) + 1024
-        r = rng.random(m) * rmax  # uniform in r  <=> areal density ~ 1/r
-        th = rng.random(m) * 2 * np.pi
-        x = sx + r * np.cos(th)
-        y = sy + r * np.sin(th)
-        z = ground_z + (rng.integers(0, 2, m) - 0.5) * vs[2] * 0.9 + 0.5 * vs[2]
-        k = np.unique(to_keys(np.stack([x, y, z], 1)))
-        k = np.setdiff1d(k, keys, assume_unique=False)
+    r0 = 2.5
+    need_ground = n_active - keys.size
+
+    def ring_keys(radii, frac):
+        out = []
+        for r in radii:
+            dth = 0.45 * min(vs[0], vs[1]) / r
+            th0 = rng.random() * 2 * np.pi
+            th = th0 + np.arange(0.0, 2 * np.pi * frac, dth)
+            rr = r + 0.35 * vs[0] * np.sin(7.0 * th + rng.random() * 6.28)        # mild radial wobble
+            x, y = sx + rr * np.cos(th), sy + rr * np.sin(th)
+            zc = np.floor(th * (3.0 + 40.0 / r)).astype(np.int64) % 2             # z index plane + {0,1} in runs
+            z = ground_z + (zc - 0.5) * vs[2] * 0.9 + 0.5 * vs[2]
+            out.append(to_keys(np.stack([x, y, z], 1)))
+        k = np.unique(np.concatenate(out)) if out else np.empty((0,), np.int64)
+        return np.setdiff1d(k, keys, assume_unique=False)
+
+    n_rings = 8
+    while True:
+        gamma = (rmax / r0) ** (1.0 / n_rings)
+        radii = r0 * gamma ** (np.arange(n_rings) + 0.5)
+        k_full = ring_keys(radii, 1.0)
+        if k_full.size >= need_ground or n_rings > 4096:
+            break
+        n_rings = int(n_rings * 1.5) + 1
+    frac = min(1.0, 1.02 * need_ground / max(k_full.size, 1))
+    k_ground = ring_keys(radii, frac) if frac < 1.0 else k_full
+    if k_ground.size < need_ground:          # top up from the full rings
+        extra = np.setdiff1d(k_full, k_ground)
+        rng.shuffle(extra)
+        k_ground = np.concatenate([k_ground, extra[:need_ground - k_ground.size]])
+    if k_ground.size > need_ground:          # trim the tail of the sorted key list (a contiguous far slab)
+        k_ground = np.sort(k_ground)[:need_ground]
+    keys = np.concatenate([keys, k_ground])
+    while keys.size < n_active:              # pathological geometry only: random fill
+        m = 4 * (n_active - keys.size) + 1024
+        xyz = np.stack([lo[0] + rng.random(m) * (hi[0] - lo[0]), lo[1] + rng.random(m) * (hi[1] - lo[1]),
+                        np.full(m, ground_z + 0.5 * vs[2])], 1)
+        k = np.setdiff1d(np.unique(to_keys(xyz)), keys)
         rng.shuffle(k)
-        keys = np.concatenate([keys, k[:need]])
+        keys = np.concatenate([keys, k[:n_active - keys.size]])
     keys = keys[:n_active]
 
     # points: 1 + Poisson(lambda) per voxel, clipped to n_points
