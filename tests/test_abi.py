@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu():
     assert lib.spx_conv_out_cap(1000, 2, i3([21, 800, 704]), i3([3, 3, 3]), i3([2, 2, 2])) == 8000
     assert lib.spx_conv_out_cap(1000, 1, i3([2, 3, 4]), i3([3, 3, 3]), i3([1, 1, 1])) == 24
     assert lib.spx_subm_rulebook_ws_bytes(16000) >= 32768 * 12
-    assert lib.spx_conv_wgrad_ws_bytes(64, 64, 27, 100000) == 64 * 27 * 64 * 64 * 4
+    assert lib.spx_conv_wgrad_ws_bytes(64, 64, 27, 100000) >= 27 * 64 * 64 * 4
 
 
 def test_ops_refuse_cpu_tensors():

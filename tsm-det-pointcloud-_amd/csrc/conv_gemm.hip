@@ -18,6 +18,8 @@
 //
 // Serves reference call sites pcdet/models/backbones_3d/spconv_backbone.py:86,93,98-100,105-107,
 // 112-114,121 (forward) and their autograd (dgrad) — spconv itself is not vendored.
+#include <stdlib.h>
+
 #include "spx_common.h"
 
 namespace {
@@ -62,8 +64,8 @@ __global__ void k_pack_plain(const float* __restrict__ w, int cout, int K, int c
 }
 
 // ---------------------------------------------------------------- MFMA implicit GEMM
-template <int CS, int CD, int MT>
-__global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ src, const float* __restrict__ wp,
+template <int CS, int CD, int MT, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_conv_mfma(const float* __restrict__ src, const float* __restrict__ wp,
                                                    const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
                                                    int64_t n, const int64_t* d_n, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, int relu,
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ src
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
   const int64_t nlive = spx_live_n(d_n, n);
-  const int64_t row_base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * MT);
+  const int64_t row_base = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * (16 * MT);
   if (row_base >= nlive) return;
 
   f32x4 acc[MT][NT];
@@ -84,6 +86,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ src
 
   const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
 
+  // NOTE (measured, profiles/r01_conv_experiments.md): explicit software pipelining of this loop (ids two offsets ahead,
+  // gathered rows one ahead) was 20 % SLOWER on MI355X at KITTI sizes — the extra live registers cost more than the
+  // hidden latency; 4-5 resident waves per SIMD already overlap the pair -> row -> MFMA chain.
   for (int k = 0; k < K; ++k) {
     const int32_t* prow = pair + (int64_t)(flip ? K - 1 - k : k) * ld;
     int32_t id[MT];
@@ -138,6 +143,147 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ src
   }
 }
 
+// ---------------------------------------------------------------- MFMA implicit GEMM, pair-compacting variant
+// For the MFMA-bound layers (c_dst >= 64) roughly half of a submanifold rulebook is -1, so the masked kernel above
+// spends half its MFMAs on zero rows.  Here a wave owns R = 64 destination rows but only 16*NTW destination COLUMNS
+// (the waves of a workgroup split the columns of the same rows, which restores the wave count that the larger row tile
+// costs).  For every offset k the wave ballot-compacts its valid (source row, local dst row) pairs into a private LDS
+// list, runs the MFMAs over 16-pair chunks of that list only, and adds each chunk's [16 x 16*NTW] result into a
+// private LDS accumulator tile at the pairs' destination rows with ds_add_f32.  For one k every destination row has at
+// most one pair and the wave walks k in order, so the summation order per output element is fixed: results are
+// bitwise reproducible, no cross-wave traffic, no barrier.
+template <int CS, int CD, int NTW>
+__global__ __launch_bounds__(256) void k_conv_mfma_cp(const float* __restrict__ src, const float* __restrict__ wp,
+                                                      const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
+                                                      int64_t n, const int64_t* d_n, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int relu,
+                                                      float* __restrict__ dst) {
+  constexpr int R = 64;                    // rows per wave
+  constexpr int NT = CD / 16;
+  constexpr int JG = CS / 16;
+  constexpr int WPT = NT / NTW;            // waves per row tile (column split)
+  constexpr int TPB = 4 / WPT;             // row tiles per 4-wave block
+  constexpr int CW = 16 * NTW;             // columns per wave
+  constexpr int LD = CW + 4;               // LDS row pitch (floats), keeps float4 alignment, spreads banks
+  static_assert(NT % NTW == 0 && 4 % WPT == 0 && WPT <= 4, "bad column split");
+  __shared__ float s_acc[4][R * LD];
+  __shared__ int32_t s_src[4][R];
+  __shared__ int32_t s_dst[4][R];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t nlive = spx_live_n(d_n, n);
+  const int64_t row0 = ((int64_t)blockIdx.x * TPB + wave / WPT) * R;
+  if (row0 >= nlive) return;               // whole wave; no barriers are used anywhere
+  const int nt0 = (wave % WPT) * NTW;      // first 16-column tile of this wave
+  float* acc = s_acc[wave];
+  int32_t* lsrc = s_src[wave];
+  int32_t* ldst = s_dst[wave];
+
+  for (int i = lane; i < R * LD / 4; i += 64) reinterpret_cast<f32x4*>(acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+  const int64_t myrow = row0 + lane;
+  int32_t id_next = myrow < nlive ? pair[(int64_t)(flip ? K - 1 : 0) * ld + myrow] : -1;
+
+  for (int k = 0; k < K; ++k) {
+    const int32_t id = id_next;
+    if (k + 1 < K) id_next = myrow < nlive ? pair[(int64_t)(flip ? K - 2 - k : k + 1) * ld + myrow] : -1;
+    const unsigned long long mask = __ballot(id >= 0);
+    if (mask == 0ull) continue;            // wave-uniform
+    const int nvalid = __popcll(mask);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    if (id >= 0) {
+      lsrc[rank] = id;
+      ldst[rank] = lane;
+    }
+    f32x4 b[NTW][JG];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) b[t][jg] = wp4[((size_t)(k * NT + nt0 + t) * JG + jg) * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+
+    const int nch = (nvalid + 15) >> 4;
+    // software pipeline over chunks: the gather of chunk ch+1 is in flight while chunk ch runs its MFMAs
+    f32x4 a_nx[JG];
+    {
+      const bool has = r < nvalid;
+      const int32_t sid = has ? lsrc[r] : 0;
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) {
+        a_nx[jg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has) a_nx[jg] = *reinterpret_cast<const f32x4*>(src + (size_t)sid * CS + q * (CS / 4) + 4 * jg);
+      }
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+      f32x4 a[JG];
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) a[jg] = a_nx[jg];
+      if (ch + 1 < nch) {
+        const int p = (ch + 1) * 16 + r;
+        const bool has = p < nvalid;
+        const int32_t sid = has ? lsrc[p] : 0;
+#pragma unroll
+        for (int jg = 0; jg < JG; ++jg) {
+          a_nx[jg] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (has) a_nx[jg] = *reinterpret_cast<const f32x4*>(src + (size_t)sid * CS + q * (CS / 4) + 4 * jg);
+        }
+      }
+      // two independent accumulation chains per column tile (MFMA dependent-issue latency 40 > issue 32 cycles)
+      f32x4 c0[NTW], c1[NTW];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) c0[t] = c1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            if ((e & 1) == 0)
+              c0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jg][e], b[t][jg][e], c0[t], 0, 0, 0);
+            else
+              c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jg][e], b[t][jg][e], c1[t], 0, 0, 0);
+          }
+      // C layout: this lane holds rows i = 4q+e (pairs ch*16 + i), column r of each 16-wide tile.  Plain LDS
+      // read-modify-write (NOT ds_add_f32: LDS float atomics serialise per lane, ~70 cycles per instruction): for one
+      // offset k every destination row occurs at most once, and only this wave touches this tile.
+      const int pbase = ch * 16 + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (pbase + e < nvalid) {
+          const int dl = ldst[pbase + e];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[dl * LD + 16 * t + r] += c0[t][e] + c1[t][e];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // epilogue: 4 lanes per row, one float4 each per 16 columns -> 64 B contiguous per row per instruction
+  __builtin_amdgcn_wave_barrier();
+  const int col4 = (lane & 3) * 4;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int colg = 16 * (nt0 + t) + col4;
+    f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + colg);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + colg);
+    for (int rr = lane >> 2; rr < R; rr += 16) {
+      const int64_t row = row0 + rr;
+      if (row >= nlive) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(acc + rr * LD + 16 * t + col4);
+      if (scale || shift) v = v * sc + sh;
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dst + row * CD + colg) = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- VALU fallback (any channel counts)
 // thread = (row, cd); weights in plain [k][cs][cd] order.  Used for conv_input (c_src = 4 or 5) and
 // for channel counts the MFMA kernels do not tile.
@@ -168,20 +314,48 @@ static int launch_mfma(const float* src, const float* wp, const int32_t* pair, i
                        hipStream_t s) {
   // rows per wave = 16*MT: larger MT amortises the weight fragment over more rows, smaller MT gives
   // more waves.  Keep >= ~8 waves per CU (2048 waves) when the problem allows it.
+  {
+    // The pair-compacting kernel wins only on low-density strided layers (measured); it is kept selectable for
+    // experiments (SPX_CONV_CP=1) and is NOT the default.
+    int use_cp = 0;
+    if (const char* e = getenv("SPX_CONV_CP")) use_cp = atoi(e);  // dev override
+    if (use_cp) {
+      constexpr int NTW = CD >= 128 ? 2 : 1;      // columns per wave: 16 (32 for 128-wide outputs)
+      constexpr int WPT = (CD / 16) / NTW;        // waves sharing a 64-row tile
+      constexpr int TPB = 4 / WPT;
+      int64_t tiles = (n + 63) / 64;
+      unsigned nb = (unsigned)((tiles + TPB - 1) / TPB);
+      hipLaunchKernelGGL((k_conv_mfma_cp<CS, CD, NTW>), dim3(nb), dim3(256), 0, s, src, wp, pair, ld, K, flip, n, d_n,
+                         scale, shift, relu, dst);
+      return SPX_OK;
+    }
+  }
+  // rows per wave = 16*MT.  Measured on MI355X (tools/kbench.py): at KITTI/Waymo sizes (<= ~260k rows) the chip is
+  // under-filled and 16 rows per wave (most waves) is fastest for every layer; only very large inputs amortise the
+  // weight fragment over more rows.
   int64_t waves4 = (n + 63) / 64, waves2 = (n + 31) / 32;
-  if (CD <= 64 && waves4 >= 2048) {
+  int mt = n >= (int64_t(1) << 20) ? 4 : (n >= (int64_t(1) << 18) ? 2 : 1);
+  if (const char* e = getenv("SPX_CONV_MT")) mt = atoi(e);  // dev override
+  if (mt == 4 && CD <= 64) {
     unsigned nb = (unsigned)((waves4 + 3) / 4);
     hipLaunchKernelGGL((k_conv_mfma<CS, CD, 4>), dim3(nb), dim3(256), 0, s, src, wp, pair, ld, K, flip, n, d_n, scale,
                        shift, relu, dst);
-  } else if (waves2 >= 1024 || CD > 64) {
+  } else if (mt >= 2) {
     unsigned nb = (unsigned)((waves2 + 3) / 4);
     hipLaunchKernelGGL((k_conv_mfma<CS, CD, 2>), dim3(nb), dim3(256), 0, s, src, wp, pair, ld, K, flip, n, d_n, scale,
                        shift, relu, dst);
   } else {
     int64_t waves1 = (n + 15) / 16;
-    unsigned nb = (unsigned)((waves1 + 3) / 4);
-    hipLaunchKernelGGL((k_conv_mfma<CS, CD, 1>), dim3(nb), dim3(256), 0, s, src, wp, pair, ld, K, flip, n, d_n, scale,
-                       shift, relu, dst);
+    int lds = 0;
+    if (const char* e = getenv("SPX_CONV_LDS")) lds = atoi(e);  // dev: cap residency -> dynamic block dispatch
+    if (lds > 0) {
+      hipLaunchKernelGGL((k_conv_mfma<CS, CD, 1, 1>), dim3((unsigned)waves1), dim3(64), lds, s, src, wp, pair, ld, K, flip,
+                         n, d_n, scale, shift, relu, dst);
+    } else {
+      unsigned nb = (unsigned)((waves1 + 3) / 4);
+      hipLaunchKernelGGL((k_conv_mfma<CS, CD, 1>), dim3(nb), dim3(256), 0, s, src, wp, pair, ld, K, flip, n, d_n, scale,
+                         shift, relu, dst);
+    }
   }
   return SPX_OK;
 }

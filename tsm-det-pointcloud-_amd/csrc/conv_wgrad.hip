@@ -20,10 +20,18 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static inline int wgrad_splits(int64_t n) {
-  int64_t s = n / 256;
+constexpr int kGroups = 4;  // 64-row rule groups fetched per iteration (independent loads in flight)
+
+// row-chunks per offset: enough one-wave blocks to fill the chip (S*K >= ~4 per SIMD), bounded by the partial-slab
+// traffic (<= 32 MiB) and by at least one full iteration (64*kGroups rows) per block
+static inline int wgrad_splits(int64_t n, int cin, int cout, int kvol) {
+  int64_t s = n / (64 * kGroups);
+  int64_t by_slab = (int64_t(32) << 20) / ((int64_t)kvol * cin * cout * 4);
+  if (s > by_slab) s = by_slab;
+  int64_t by_blocks = 4096 / kvol;          // ~4 one-wave blocks per SIMD is plenty; more only lengthens the reduce
+  if (by_blocks < 8) by_blocks = 8;
+  if (s > by_blocks) s = by_blocks;
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
   return (int)s;
 }
 
@@ -32,8 +40,8 @@ __global__ __launch_bounds__(64) void k_wgrad_mfma(const float* __restrict__ in,
                                                    const float* __restrict__ dout, int cout,
                                                    const int32_t* __restrict__ pair, int64_t ld, int64_t n,
                                                    const int64_t* d_n, int64_t chunk, float* __restrict__ slab) {
-  __shared__ int32_t q_src[64];
-  __shared__ int32_t q_dst[64];
+  __shared__ int32_t q_src[64 * kGroups];
+  __shared__ int32_t q_dst[64 * kGroups];
   const int lane = threadIdx.x;
   const int c = lane & 15, q = lane >> 4;
   const int k = blockIdx.y, K = gridDim.y;
@@ -48,17 +56,25 @@ __global__ __launch_bounds__(64) void k_wgrad_mfma(const float* __restrict__ in,
     for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int32_t* prow = pair + (int64_t)k * ld;
-  for (int64_t base = r0; base < r1; base += 64) {
-    int64_t row = base + lane;
-    int32_t id = row < r1 ? prow[row] : -1;
-    unsigned long long mask = __ballot(id >= 0);
-    if (mask == 0ull) continue;
-    int nvalid = __popcll(mask);
-    int rank = __popcll(mask & ((1ull << lane) - 1ull));
-    if (id >= 0) {
-      q_src[rank] = id;
-      q_dst[rank] = (int32_t)row;
+  for (int64_t base = r0; base < r1; base += 64 * kGroups) {
+    int32_t id[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      int64_t row = base + 64 * g + lane;
+      id[g] = row < r1 ? prow[row] : -1;
     }
+    int nvalid = 0;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      unsigned long long mask = __ballot(id[g] >= 0);
+      int rank = nvalid + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+      if (id[g] >= 0) {
+        q_src[rank] = id[g];
+        q_dst[rank] = (int32_t)(base + 64 * g + lane);
+      }
+      nvalid += __popcll(mask);
+    }
+    if (nvalid == 0) continue;
     __builtin_amdgcn_wave_barrier();
     for (int st = 0; st * 4 < nvalid; ++st) {
       int p = 4 * st + q;
@@ -98,22 +114,31 @@ __global__ __launch_bounds__(64) void k_wgrad_mfma(const float* __restrict__ in,
       }
 }
 
-// dw[co][k][ci] = sum_s slab[s][k][ci][co]   (fixed order over s)
-__global__ void k_wgrad_reduce(const float* __restrict__ slab, int S, int K, int cin, int cout,
-                               float* __restrict__ dw) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int per = cin * cout;
-  if (t >= K * per) return;
-  int co = t % cout, ci = (t / cout) % cin, k = t / per;
+// dw[co][k][ci] = sum_s slab[s][k][ci][co]   (fixed order over s).  Block = 64 consecutive elements x 4 S-slices:
+// coalesced 256-B reads, 4 independent partial sums per element, combined through LDS in slice order.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int S, int K, int cin, int cout,
+                                                      float* __restrict__ dw) {
+  __shared__ float part[4][64];
+  const int per = cin * cout;
+  const int total = K * per;
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + e;
   float s = 0.f;
-  for (int j = 0; j < S; ++j) s += slab[((size_t)j * K + k) * per + (size_t)ci * cout + co];
-  dw[((size_t)co * K + k) * cin + ci] = s;
+  if (t < total)
+    for (int j = sl; j < S; j += 4) s += slab[(size_t)j * total + t];
+  part[sl][e] = s;
+  __syncthreads();
+  if (sl == 0 && t < total) {
+    float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+    int co = t % cout, ci = (t / cout) % cin, k = t / per;
+    dw[((size_t)co * K + k) * cin + ci] = v;
+  }
 }
 
 }  // namespace
 
 extern "C" size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n_out) {
-  return spx_align((size_t)wgrad_splits(n_out) * kvol * cin * cout * sizeof(float));
+  return spx_align((size_t)wgrad_splits(n_out, cin, cout, kvol) * kvol * cin * cout * sizeof(float));
 }
 
 #define SPX_WG_CASE(A, B)                                                                                          \
@@ -137,7 +162,7 @@ extern "C" int spx_conv_wgrad(const float* in, int cin, const float* dout, int c
     (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cout * kvol * cin, s);
     return SPX_OK;
   }
-  int S = wgrad_splits(n_out);
+  int S = wgrad_splits(n_out, cin, cout, kvol);
   int64_t chunk = ((n_out + S - 1) / S + 63) / 64 * 64;
   float* slab = reinterpret_cast<float*>(ws);
   int MI = (cin + 15) / 16, NJ = (cout + 15) / 16;
@@ -164,7 +189,7 @@ extern "C" int spx_conv_wgrad(const float* in, int cin, const float* dout, int c
   SPX_WG_CASE(8, 8)
   if (!launched) return SPX_ERR_UNSUPPORTED;
   int total = kvol * cin * cout;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, s, slab, S, kvol, cin, cout, dw);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 63) / 64), dim3(256), 0, s, slab, S, kvol, cin, cout, dw);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }
