@@ -232,6 +232,21 @@ class KernelTimer(object):
         return fam
 
 
+def pmc_traffic(prefix):
+    """HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md §HBM) of the kernels whose name starts with
+    `prefix`, from the newest profiles/r*_pmc_traffic.json (written by tools/pmc_traffic.sh on the same bench command in
+    separate --pmc passes).  None when no such file travels with the repo."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    n = sum(v["launches"] for k, v in d.items() if k.startswith(prefix))
+    if n == 0:
+        return None
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in d.items() if k.startswith(prefix)) / n
+
+
 def roofline_of(fam):
     """Dominant hand-written kernel family by time -> the roofline object of the contract."""
     name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
@@ -241,7 +256,8 @@ def roofline_of(fam):
     else:
         ach, peak, unit, bound = d["bytes"] / t / 1e9, HBM_PEAK / 1e9, "GB/s", "hbm"
     return {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-            "frac": round(ach / peak, 4), "traffic": None,
+            "frac": round(ach / peak, 4),
+            "traffic": pmc_traffic({"conv_gemm[mfma]": "k_conv_mfma", "conv_wgrad": "k_wgrad_mfma"}.get(name, "?")),
             "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches_per_step"],
             "algorithmic_flops_per_launch": d["flops"] / d["launches"],
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"]}

@@ -1,0 +1,31 @@
+#!/bin/bash
+# HBM traffic of the libspx kernels from PMC counters, collected as MI355X_MICROARCH.md prescribes: separate --pmc passes
+# (FETCH_SIZE, WRITE_SIZE), no tracing domains; FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as is.
+# usage (GPU box): tools/pmc_traffic.sh <round-tag>      -> gpurun_out/pmc_traffic_<tag>.json
+tag=${1:-r01}
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 5 400 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/$c.log 2>&1
+  echo "pass $c done"
+done
+python3 - <<PY
+import csv, glob, json, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$out/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        if "anonymous namespace" not in n or "k_" not in n: continue
+        short = n.split("::")[-1].split("(")[0]
+        acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for k, d in acc.items():
+    f = d.get("FETCH_SIZE", [0]); w = d.get("WRITE_SIZE", [0])
+    fetch = sum(f) / max(len(f), 1) * 1024.0; write = sum(w) / max(len(w), 1) * 1024.0
+    res[k] = {"launches": len(f), "fetch_bytes_raw_per_launch": fetch, "write_bytes_per_launch": write,
+              "hbm_bytes_per_launch": 2.0 * fetch + write}
+json.dump(res, open("$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic_$tag.json", "w"), indent=1, sort_keys=True)
+for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
+    print("%-40s launches %4d  fetch(raw) %9.2f MB  write %9.2f MB  hbm(2F+W) %9.2f MB" % (k[:40], v["launches"], v["fetch_bytes_raw_per_launch"]/1e6, v["write_bytes_per_launch"]/1e6, v["hbm_bytes_per_launch"]/1e6))
+PY

@@ -39,14 +39,21 @@ template <int MI, int NJ>
 __global__ __launch_bounds__(64) void k_wgrad_mfma(const float* __restrict__ in, int cin,
                                                    const float* __restrict__ dout, int cout,
                                                    const int32_t* __restrict__ pair, int64_t ld, int64_t n,
-                                                   const int64_t* d_n, int64_t chunk, float* __restrict__ slab) {
+                                                   const int64_t* d_n, int64_t chunk, int S, int K, float* __restrict__ slab) {
   __shared__ int32_t q_src[64 * kGroups];
   __shared__ int32_t q_dst[64 * kGroups];
   const int lane = threadIdx.x;
   const int c = lane & 15, q = lane >> 4;
-  const int k = blockIdx.y, K = gridDim.y;
+  // XCD-aware block -> (chunk, offset) map: blocks b and b+8 share an XCD (and its L2).  The K blocks of one row chunk
+  // all read the same dout rows and neighbouring input rows, so they are given ids of one residue class mod 8 and
+  // consecutive positions inside it: one XCD fetches the chunk once instead of up to K times (PMC before: 158 MB
+  // fetched per 64->64 launch against 38 MB compulsory).
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int k = j % K;
+  const int chunk_id = xcd + 8 * (j / K);
+  if (chunk_id >= S) return;
   const int64_t nlive = spx_live_n(d_n, n);
-  int64_t r0 = (int64_t)blockIdx.x * chunk;
+  int64_t r0 = (int64_t)chunk_id * chunk;
   int64_t r1 = r0 + chunk < nlive ? r0 + chunk : nlive;
 
   f32x4 acc[MI][NJ];
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(64) void k_wgrad_mfma(const float* __restrict__ in,
   }
 
   // partial[s][k][ci][co]; C layout: row(ci) = 16mi + 4q + e, col(co) = 16nj + c
-  float* out = slab + ((size_t)blockIdx.x * K + k) * cin * cout;
+  float* out = slab + ((size_t)chunk_id * K + k) * cin * cout;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -143,8 +150,8 @@ extern "C" size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n
 
 #define SPX_WG_CASE(A, B)                                                                                          \
   if (MI == A && NJ == B) {                                                                                        \
-    hipLaunchKernelGGL((k_wgrad_mfma<A, B>), dim3(S, kvol), dim3(64), 0, s, in, cin, dout, cout, pair, pair_ld, n_out, \
-                       d_n_out, chunk, slab);                                                                      \
+    hipLaunchKernelGGL((k_wgrad_mfma<A, B>), dim3(8 * kvol * ((S + 7) / 8)), dim3(64), 0, s, in, cin, dout, cout, pair, pair_ld, \
+                       n_out, d_n_out, chunk, S, kvol, slab);                                                                      \
     launched = true;                                                                                               \
   }
 
