@@ -170,6 +170,24 @@ int spx_densify(const float *feat, const int32_t *idx, int64_t n, const int64_t 
 int spx_densify_bwd(const float *ddense, const int32_t *idx, int64_t n, const int64_t *d_n, int c, int batch,
                     const int32_t *shape, int layout, float *dfeat, spx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * 6. Rotated-BEV IoU and NMS  (post-processing)
+ *    replaces: iou3d_nms_cuda.boxes_overlap_bev_gpu / boxes_iou_bev_gpu / nms_gpu / nms_normal_gpu, reference
+ *      pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:236-325, src/iou3d_nms.cpp:53-190, called from
+ *      pcdet/ops/iou3d_nms/iou3d_nms_utils.py:48-118 by model_nms_utils.py:6-87.
+ *    boxes are device [n,7] fp32 (x,y,z,dx,dy,dz,heading).
+ *    spx_boxes_iou_bev : out[n,m] = BEV IoU (overlap_only != 0: intersection AREA) of every pair.
+ *    spx_nms_bev       : boxes must already be sorted by descending score; keep[0..*d_num_keep) receives the kept
+ *                        positions in ascending order (greedy: a box is kept iff no earlier kept box has IoU > thresh).
+ *                        axis_aligned != 0 uses the heading-less IoU of nms_normal_gpu.  The suppression mask and its
+ *                        reduction stay on the device (the reference copies the mask to the host and reduces there).
+ * ---------------------------------------------------------------------------------------------- */
+int spx_boxes_iou_bev(const float *boxes_a, int64_t n, const float *boxes_b, int64_t m, int overlap_only, float *out,
+                      spx_stream_t stream);
+size_t spx_nms_ws_bytes(int64_t n);
+int spx_nms_bev(const float *boxes, int64_t n, float thresh, int axis_aligned, int64_t *keep, int64_t *d_num_keep,
+                void *ws, size_t ws_bytes, spx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,7 +120,18 @@ def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False)
     return ddense[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]].contiguous()
 
 
-_NAMES = ["voxelize", "mean_vfe", "subm_rulebook", "conv_rulebook", "pack_weight", "conv_gemm", "conv_wgrad",
+def boxes_iou_bev(boxes_a, boxes_b, overlap_only=False):
+    return torch.from_numpy(orc.boxes_iou_bev(_np(boxes_a), _np(boxes_b), overlap_only))
+
+
+def nms_bev(boxes_sorted, thresh, axis_aligned=False):
+    keep = orc.nms_bev(_np(boxes_sorted), thresh, axis_aligned)
+    out = torch.zeros((max(boxes_sorted.shape[0], 1),), dtype=torch.int64)
+    out[:keep.shape[0]] = torch.from_numpy(keep)
+    return out, torch.tensor([keep.shape[0]], dtype=torch.int64)
+
+
+_NAMES = ["boxes_iou_bev", "nms_bev", "voxelize", "mean_vfe", "subm_rulebook", "conv_rulebook", "pack_weight", "conv_gemm", "conv_wgrad",
           "densify", "densify_bwd"]
 
 

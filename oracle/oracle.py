@@ -238,3 +238,23 @@ def backbone8x_forward(feat, idx, batch, sparse_shape, weights, bn, train_bn=Fal
         out[name] = (cur_f, cur_i, list(shape))
     out["rulebooks"] = books
     return out
+
+
+# --------------------------------------------------------------------------- f-1: rotated BEV IoU / NMS
+
+def boxes_iou_bev(a, b, overlap_only=False):
+    a = np.ascontiguousarray(a, np.float32)[:, :7].copy()
+    b = np.ascontiguousarray(b, np.float32)[:, :7].copy()
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    lib().orc_boxes_iou_bev(_f(a), ctypes.c_int64(a.shape[0]), _f(b), ctypes.c_int64(b.shape[0]), int(overlap_only), _f(out))
+    return out
+
+
+def nms_bev(boxes_sorted, thresh, axis_aligned=False):
+    """boxes already sorted by descending score -> kept positions (ascending)."""
+    b = np.ascontiguousarray(boxes_sorted, np.float32)[:, :7].copy()
+    keep = np.zeros((max(b.shape[0], 1),), np.int64)
+    lib().orc_nms_bev.restype = ctypes.c_int64
+    n = lib().orc_nms_bev(_f(b), ctypes.c_int64(b.shape[0]), ctypes.c_float(thresh), int(axis_aligned),
+                          keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+    return keep[:n].copy()

@@ -335,3 +335,62 @@ def test_mean_vfe_standalone(orc):
     vox = torch.randn(1000, 5, 4, generator=g) * (torch.arange(5)[None, :, None] < num[:, None, None])
     out = ops.mean_vfe(vox.to(_dev()), num.to(_dev()))
     _close(out.cpu().numpy(), orc.mean_vfe(vox.numpy(), num.numpy()), tol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ rotated BEV IoU / NMS (row f-1)
+
+def _rand_boxes(g, n, spread, cluster=False):
+    if cluster:
+        centres = torch.rand(max(n // 40, 1), 2, generator=g) * spread
+        xy = centres[torch.randint(0, centres.shape[0], (n,), generator=g)] + torch.randn(n, 2, generator=g) * 0.7
+    else:
+        xy = torch.rand(n, 2, generator=g) * spread
+    dims = torch.rand(n, 2, generator=g) * torch.tensor([3.5, 1.5]) + torch.tensor([0.6, 0.5])
+    return torch.cat([xy, torch.zeros(n, 1), dims, torch.ones(n, 1) * 1.5, (torch.rand(n, 1, generator=g) - 0.5) * 6.3], 1)
+
+
+def test_boxes_iou_bev_vs_oracle(orc):
+    from spx import ops
+    g = torch.Generator().manual_seed(21)
+    a = _rand_boxes(g, 300, 30.0, cluster=True)
+    b = a[:257].clone()
+    b[:, :2] += torch.randn(257, 2, generator=g) * 0.8      # overlapping neighbours of a
+    b[:, 6] += torch.randn(257, generator=g)
+    for overlap_only in (False, True):
+        out = ops.boxes_iou_bev(a.to(_dev()), b.to(_dev()), overlap_only=overlap_only).cpu().numpy()
+        ref = orc.boxes_iou_bev(a.numpy(), b.numpy(), overlap_only)
+        assert (ref > 0).mean() > 0.005
+        assert np.abs(out - ref).max() < 2e-5
+    # identical, contained and axis-aligned special cases (closed forms checked in tests/test_oracle_golden.py)
+    same = ops.boxes_iou_bev(a[:50].to(_dev()), a[:50].to(_dev())).diagonal().cpu().numpy()
+    assert np.abs(same - 1.0).max() < 1e-4
+
+
+@pytest.mark.parametrize("n,cluster,thresh,normal", [(1, False, 0.1, False), (64, True, 0.1, False), (65, True, 0.01, False),
+                                                     (1000, False, 0.01, False), (3000, True, 0.01, False),
+                                                     (4096, True, 0.5, False), (5000, True, 0.3, False),
+                                                     (2000, True, 0.2, True)])
+def test_nms_bev_vs_oracle(n, cluster, thresh, normal, orc):
+    """Greedy NMS keep list (integer result) must equal the oracle's exactly."""
+    from spx import ops
+    g = torch.Generator().manual_seed(1000 + n)
+    boxes = _rand_boxes(g, n, 70.0 if not cluster else 40.0, cluster)
+    keep, cnt = ops.nms_bev(boxes.to(_dev()), thresh, axis_aligned=normal)
+    got = keep[:int(cnt.item())].cpu().numpy()
+    ref = orc.nms_bev(boxes.numpy(), thresh, normal)
+    assert 0 < ref.shape[0] <= n
+    assert np.array_equal(got, ref)
+
+
+def test_nms_utils_api(orc):
+    """iou3d_nms_utils.nms_gpu signature: unsorted scores in, indices into the ORIGINAL order out."""
+    from pcdet_amd.ops.iou3d_nms import iou3d_nms_utils
+    g = torch.Generator().manual_seed(77)
+    boxes = _rand_boxes(g, 1500, 40.0, True)
+    scores = torch.rand(1500, generator=g)
+    sel, _ = iou3d_nms_utils.nms_gpu(boxes.to(_dev()), scores.to(_dev()), 0.1, pre_maxsize=1024)
+    order = scores.sort(0, descending=True)[1][:1024]
+    ref = order[torch.from_numpy(orc.nms_bev(boxes[order].numpy(), 0.1))]
+    assert torch.equal(sel.cpu(), ref)
+    iou3d = iou3d_nms_utils.boxes_iou3d_gpu(boxes[:20].to(_dev()), boxes[:20].to(_dev()))
+    assert float((iou3d.diagonal() - 1).abs().max()) < 1e-4

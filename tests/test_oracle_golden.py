@@ -88,3 +88,26 @@ def test_oracle_backbone8x_shapes(orc):
     assert out["conv3.2.0"][2] == [11, 400, 352]
     assert out["conv4.2.0"][2] == [5, 200, 176]
     assert out["conv_out.0"][2] == [2, 200, 176] and out["conv_out.0"][0].shape[1] == 128
+
+
+def test_oracle_rotated_iou_known_answers(orc):
+    """Rotated BEV IoU restatement (iou3d_cpu.cpp:66-229) on cases with closed-form answers."""
+    def box(x, y, dx, dy, r):
+        return [x, y, 0.0, dx, dy, 1.0, r]
+    a = np.array([box(0, 0, 2, 2, 0.0)], np.float32)
+    b = np.array([box(0, 0, 2, 2, 0.0), box(1, 0, 2, 2, 0.0), box(5, 5, 1, 1, 0.3), box(0, 0, 2, 2, np.pi / 4),
+                  box(0, 0, 4, 1, np.pi / 2), box(0.5, 0.5, 1, 1, np.pi)], np.float32)
+    iou = orc.boxes_iou_bev(a, b)[0]
+    ov = orc.boxes_iou_bev(a, b, overlap_only=True)[0]
+    assert abs(iou[0] - 1.0) < 1e-6
+    assert abs(ov[1] - 2.0) < 1e-5 and abs(iou[1] - 2.0 / 6.0) < 1e-5          # half overlap
+    assert ov[2] == 0.0 and iou[2] == 0.0                                       # disjoint
+    assert abs(ov[3] - 8.0 * (np.sqrt(2.0) - 1.0)) < 1e-4                       # square vs 45-degree square: octagon
+    assert abs(ov[4] - 2.0) < 1e-5                                              # 4x1 turned 90 degrees inside-crossing
+    assert abs(ov[5] - 1.0) < 1e-5 and abs(iou[5] - 0.25) < 1e-5                # contained box
+    # greedy NMS semantics: box 1 suppresses its heavy overlaps only
+    boxes = np.array([box(0, 0, 2, 2, 0), box(0.1, 0, 2, 2, 0), box(3, 0, 2, 2, 0), box(3.05, 0.05, 2, 2, 0.1),
+                      box(10, 10, 1, 1, 0)], np.float32)
+    assert orc.nms_bev(boxes, 0.5).tolist() == [0, 2, 4]
+    assert orc.nms_bev(boxes, 0.99).tolist() == [0, 1, 2, 3, 4]
+    assert orc.nms_bev(boxes[:0], 0.5).tolist() == []

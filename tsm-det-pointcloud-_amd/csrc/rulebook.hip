@@ -197,17 +197,31 @@ __global__ void k_scan_expand(const uint64_t* __restrict__ bits, int64_t nwords,
     if (w0 + j >= nwords) break;
     prefix[w0 + j] = run;
     uint64_t m = wv[j];
+    if (m == 0ull) continue;
+    // decode the word's first cell ONCE (64-bit divisions are ~100 instructions each on the GPU), then walk the set
+    // bits with 32-bit carries: the 64 cells of a word are consecutive in x and wrap into y / z / batch
+    int64_t key0 = (w0 + j) << 6;
+    int x0 = (int)(key0 % out_shape.v[2]);
+    int64_t t = key0 / out_shape.v[2];
+    int y0 = (int)(t % out_shape.v[1]);
+    t /= out_shape.v[1];
+    int z0 = (int)(t % out_shape.v[0]);
+    int b0 = (int)(t / out_shape.v[0]);
     while (m) {
       int b = __ffsll((unsigned long long)m) - 1;
       m &= m - 1;
-      int64_t key = ((w0 + j) << 6) + b;
       if ((int64_t)run < cap) {
-        int x = (int)(key % out_shape.v[2]);
-        int64_t t = key / out_shape.v[2];
-        int y = (int)(t % out_shape.v[1]);
-        t /= out_shape.v[1];
-        int z = (int)(t % out_shape.v[0]);
-        int bb = (int)(t / out_shape.v[0]);
+        int x = x0 + b, y = y0, z = z0, bb = b0;
+        while (x >= out_shape.v[2]) {
+          x -= out_shape.v[2];
+          if (++y == out_shape.v[1]) {
+            y = 0;
+            if (++z == out_shape.v[0]) {
+              z = 0;
+              ++bb;
+            }
+          }
+        }
         reinterpret_cast<int4*>(out_idx)[run] = make_int4(bb, z, y, x);
       }
       ++run;

@@ -43,6 +43,9 @@ SIGNATURES = {
     "spx_conv_wgrad": (_int, [_vp, _int, _vp, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "spx_densify": (_int, [_vp, _vp, _i64, _vp, _int, _int, _i32p, _int, _vp, _vp]),
     "spx_densify_bwd": (_int, [_vp, _vp, _i64, _vp, _int, _int, _i32p, _int, _vp, _vp]),
+    "spx_boxes_iou_bev": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp]),
+    "spx_nms_ws_bytes": (_sz, [_i64]),
+    "spx_nms_bev": (_int, [_vp, _i64, ctypes.c_float, _int, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -65,15 +65,47 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for module in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if is_spconv_module(module):
+                fuse = _fusable_tail(module, mods, i) if isinstance(input, SparseConvTensor) else None
+                if fuse is not None:
+                    # inference: BatchNorm1d (running stats) + ReLU folded into the conv kernel's epilogue —
+                    # one launch instead of three and no extra pass over the features
+                    scale, shift, relu, consumed = fuse
+                    input = module(input, fused=(scale, shift, relu))
+                    i += consumed
+                    continue
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
                     input = input.replace_feature(module(input.features))
             else:
                 input = module(input)
+            i += 1
         return input
+
+
+def _fusable_tail(conv, mods, i):
+    """(scale, shift, relu, modules consumed) when mods[i:] is SparseConvolution, BatchNorm1d(eval)[, ReLU] and no
+    autograd graph is being recorded (the fused epilogue has no backward); else None."""
+    if not is_sparse_conv(conv) or torch.is_grad_enabled() or i + 1 >= len(mods):
+        return None
+    bn = mods[i + 1]
+    if not isinstance(bn, nn.BatchNorm1d) or bn.training or bn.running_mean is None:
+        return None
+    with torch.no_grad():
+        inv = torch.rsqrt(bn.running_var + bn.eps)
+        scale = inv * bn.weight if bn.affine else inv
+        shift = -bn.running_mean * scale
+        if bn.affine:
+            shift = shift + bn.bias
+        if conv.bias is not None:
+            shift = shift + conv.bias * scale
+    relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+    return scale.contiguous(), shift.contiguous(), relu, (3 if relu else 2)
 
 
 def _triple(v, ndim=3):
@@ -153,13 +185,18 @@ class SparseConvolution(SparseModule):
             x.indice_dict[self.indice_key] = rb
         return rb
 
-    def forward(self, x):
+    def forward(self, x, fused=None):
         assert isinstance(x, SparseConvTensor)
         feats = x.features
         if feats.shape[1] != self.in_channels:
             raise ValueError("channel size mismatch: got %d, conv expects %d" % (feats.shape[1], self.in_channels))
         rb = self._rulebook(x)
-        out_feats = F_.sparse_conv(feats, self.weight, self.bias, rb, inverse=self.inverse)
+        if fused is not None:
+            scale, shift, relu = fused      # shift already contains the conv bias
+            out_feats = F_.sparse_conv(feats, self.weight, None, rb, inverse=self.inverse, scale=scale, shift=shift,
+                                       relu=relu)
+        else:
+            out_feats = F_.sparse_conv(feats, self.weight, self.bias, rb, inverse=self.inverse)
         if self.inverse:
             out = SparseConvTensor(out_feats, self._inverse_indices(x, rb), rb.in_shape,
                                    x.batch_size, x.grid, x.voxel_num, x.indice_dict, x.benchmark)

@@ -230,3 +230,33 @@ def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False)
     check(lib.spx_densify_bwd(_ptr(dd), _ptr(indices), n, None, c, batch_size, i3(spatial_shape),
                               1 if channels_last else 0, _ptr(dfeat), _stream(ddense)), "spx_densify_bwd")
     return dfeat
+
+
+# ------------------------------------------------------------------------------------------- rotated BEV IoU / NMS
+
+def boxes_iou_bev(boxes_a, boxes_b, overlap_only=False):
+    """(N,7),(M,7) [x,y,z,dx,dy,dz,heading] -> (N,M) BEV IoU (or intersection area)."""
+    _need_gpu(boxes_a, boxes_b)
+    lib = _lib.load()
+    a = boxes_a[:, :7].contiguous().float()
+    b = boxes_b[:, :7].contiguous().float()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    check(lib.spx_boxes_iou_bev(_ptr(a), a.shape[0], _ptr(b), b.shape[0], int(bool(overlap_only)), _ptr(out), _stream(a)),
+          "spx_boxes_iou_bev")
+    return out
+
+
+def nms_bev(boxes_sorted, thresh, axis_aligned=False):
+    """boxes (N,7) already sorted by descending score -> (keep positions int64 [N] on device, count tensor int64[1]).
+    No host sync here; the caller slices keep[:count]."""
+    _need_gpu(boxes_sorted)
+    lib = _lib.load()
+    b = boxes_sorted[:, :7].contiguous().float()
+    n = b.shape[0]
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=b.device)
+    cnt = torch.zeros((1,), dtype=torch.int64, device=b.device)
+    wsb = lib.spx_nms_ws_bytes(n)
+    ws = workspace(b.device, wsb)
+    check(lib.spx_nms_bev(_ptr(b), n, float(thresh), int(bool(axis_aligned)), _ptr(keep), _ptr(cnt), _ptr(ws), wsb,
+                          _stream(b)), "spx_nms_bev")
+    return keep, cnt
