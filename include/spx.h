@@ -188,6 +188,26 @@ size_t spx_nms_ws_bytes(int64_t n);
 int spx_nms_bev(const float *boxes, int64_t n, float thresh, int axis_aligned, int64_t *keep, int64_t *d_num_keep,
                 void *ws, size_t ws_bytes, spx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * 7. Anchor target assignment (training)
+ *    replaces: AxisAlignedTargetAssigner.assign_targets, reference
+ *      pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:36-210 (per-sample / per-class python
+ *      loops over torch ops), incl. boxes3d_nearest_bev_iou (pcdet/utils/box_utils.py:249-298) and
+ *      ResidualCoder.encode_torch (pcdet/utils/box_coder_utils.py:13-43); SECOND settings only
+ *      (POS_FRACTION < 0, NORM_BY_NUM_EXAMPLES False, MATCH_HEIGHT False, single head).
+ *    anchors   device [n_sets][anchors_per_set][7], every set laid out (z=1, y, x, size, rot) as AnchorGenerator emits
+ *    gt_boxes  device [batch][max_gt][8] = (x,y,z,dx,dy,dz,heading,class 1..n_classes), zero padded
+ *    d_set_class device int32[n_sets]: 0-based class index each anchor set is matched against
+ *    outputs in the head's anchor order (y, x, set, within-location), A_total = n_sets * anchors_per_set:
+ *      labels int32 [batch][A_total] (class id / 0 background / -1 ignored), targets fp32 [batch][A_total][7],
+ *      weights fp32 [batch][A_total] (1 where labels > 0)
+ * ---------------------------------------------------------------------------------------------- */
+size_t spx_assign_targets_ws_bytes(int batch, int n_sets, int max_gt);
+int spx_assign_targets(const float *anchors, int n_sets, int64_t anchors_per_set, int per_location,
+                       const float *gt_boxes, int batch, int max_gt, const int32_t *d_set_class, int n_classes,
+                       const float *d_matched, const float *d_unmatched, int32_t *labels, float *targets,
+                       float *weights, void *ws, size_t ws_bytes, spx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -255,3 +255,28 @@ def test_eval_post_processing_end_to_end():
         assert torch.equal(pg["pred_labels"].cpu(), pc["pred_labels"])
         assert torch.equal(pg["pred_boxes"].cpu(), pc["pred_boxes"])
         assert float((pg["pred_scores"].cpu() - pc["pred_scores"]).abs().max()) < 1e-6   # sigmoid: 1 ulp across devices
+
+
+@pytest.mark.parametrize("cfg_id,batch", [(0, 3), (2, 4)])
+def test_fused_target_assigner_matches_torch_formulation(cfg_id, batch):
+    """csrc/assign.hip against the batched torch restatement (itself pinned to the reference's loop implementation by
+    tests/test_ref_modules.py): integer labels and weights exactly, regression targets to 1e-5."""
+    from pcdet_amd.datasets import synthetic
+    _cfg, ds, model = _build(cfg_id=cfg_id)
+    dev = torch.device("cuda:0")
+    head = model.dense_head.to(dev)
+    b = synthetic.make_batch(cfg_id, batch)
+    gt = torch.from_numpy(b["gt_boxes"]).to(dev)
+    # edge cases: an all-padding frame, an interior all-zero row (class id 0 -> class_names[-1] quirk), a far-away box
+    gt = torch.cat([gt, torch.zeros(1, gt.shape[1], 8, device=dev)], 0)
+    gt[0, 1] = 0.0
+    gt[1, 0, :2] += 500.0
+    ta = head.target_assigner
+    got = ta.assign_targets(head.anchors, gt)
+    ref = ta.assign_targets_torch(head.anchors, gt)
+    assert got["box_cls_labels"].dtype == torch.int32
+    assert torch.equal(got["box_cls_labels"], ref["box_cls_labels"])
+    assert torch.equal(got["reg_weights"], ref["reg_weights"])
+    assert float((got["box_reg_targets"] - ref["box_reg_targets"]).abs().max()) < 1e-5
+    assert int((ref["box_cls_labels"] > 0).sum()) > 0 and int((ref["box_cls_labels"] < 0).sum()) > 0
+    assert int((ref["box_cls_labels"][-1] != 0).sum()) == 0

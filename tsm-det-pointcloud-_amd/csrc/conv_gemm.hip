@@ -20,6 +20,8 @@
 // 112-114,121 (forward) and their autograd (dgrad) — spconv itself is not vendored.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "spx_common.h"
 
 namespace {
@@ -284,6 +286,190 @@ __global__ __launch_bounds__(256) void k_conv_mfma_cp(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------- MFMA implicit GEMM, block-cooperative variant
+// A block owns R = 64 destination rows; its WPT waves split the destination COLUMNS (16*NTW each).  Per kernel offset k:
+//   * wave 0 ballot-compacts the block's valid (source row, local dst row) pairs into an LDS list (two offsets ahead);
+//   * ALL threads gather the listed source rows — 16 consecutive threads read one 256-B row, fully coalesced — into
+//     registers one offset ahead and drop them into a shared LDS tile after the barrier (the gather of offset k+1 is in
+//     flight while offset k runs its MFMAs);
+//   * every wave reads its A fragments from that tile (ds_read_b128), multiplies with ITS OWN column slice of W_k
+//     (register double-buffered, loaded one offset ahead) over 16-pair chunks of the list only — no MFMA is spent on
+//     rows without a neighbour — and adds the [16 x 16*NTW] result into its private LDS accumulator at the pairs'
+//     destination rows (plain read-modify-write: one pair per destination row per offset, one owner wave per column
+//     slice, offsets in order => fixed summation order, bitwise reproducible).
+// Two barriers per offset.  LDS: (CS+4)*64*4 + WPT*64*(16*NTW+4)*4 + lists  (39 KiB for 64->64: 4 blocks per CU).
+template <int CS, int CD, int NTW, int R>
+__global__ __launch_bounds__(64 * (CD / 16 / NTW)) void k_conv_mfma_bc(
+    const float* __restrict__ src, const float* __restrict__ wp, const int32_t* __restrict__ pair, int64_t ld, int K,
+    int flip, int64_t n, const int64_t* d_n, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+    float* __restrict__ dst) {
+  constexpr int NT = CD / 16, JG = CS / 16;
+  constexpr int WPT = NT / NTW, NTHR = 64 * WPT;
+  constexpr int CW = 16 * NTW, LDC = CW + 4, LDA = CS + 4;
+  constexpr int PPR = CS / 4;                        // float4 pieces per source row
+  constexpr int NPIECE = (R * PPR + NTHR - 1) / NTHR;  // pieces per thread when all 64 rows are valid
+  static_assert(NT % NTW == 0 && WPT >= 1 && WPT <= 4, "bad column split");
+  constexpr int LA = 3;                              // gather look-ahead (offsets in flight per block)
+  constexpr int NS = LA + 2;                         // list slots: k (in use) .. k+LA (issued) and k+LA+1 (being built)
+  __shared__ float s_a[R * LDA];
+  __shared__ float s_acc[WPT][R * LDC];
+  __shared__ int32_t s_src[NS][R];
+  __shared__ int32_t s_dst[NS][R];
+  __shared__ int32_t s_cnt[NS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t nlive = spx_live_n(d_n, n);
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  if (row0 >= nlive) return;   // uniform for the whole block
+  const int nt0 = wave * NTW;
+  float* acc = s_acc[wave];
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+  const f32x4* src4 = reinterpret_cast<const f32x4*>(src);
+
+  for (int i = lane; i < R * LDC / 4; i += 64) reinterpret_cast<f32x4*>(acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- rule entries and pair lists (wave 0 only; lane <-> destination row)
+  const int64_t myrow = row0 + lane;
+  auto load_id = [&](int k) -> int32_t {
+    return (k < K && lane < R && myrow < nlive) ? pair[(int64_t)(flip ? K - 1 - k : k) * ld + myrow] : -1;
+  };
+  auto build_list = [&](int32_t id, int slot) {
+    const unsigned long long mask = __ballot(id >= 0);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    if (id >= 0) {
+      s_src[slot][rank] = id;
+      s_dst[slot][rank] = lane;
+    }
+    if (lane == 0) s_cnt[slot] = __popcll(mask);
+  };
+  int32_t id_a = -1, id_b = -1;   // entries of offsets k+LA+1 and k+LA+2 while offset k computes
+  if (wave == 0) {
+#pragma unroll
+    for (int m = 0; m <= LA; ++m) build_list(load_id(m), m);
+    id_a = load_id(LA + 1);
+    id_b = load_id(LA + 2);
+  }
+  __syncthreads();
+
+  // ---- gather: piece p of a list = (row p / PPR, float4 part p % PPR); 16 consecutive threads read one source row
+  f32x4 g[LA][NPIECE];
+  auto gather_issue = [&](int m, f32x4* gs) {        // rows of offset m -> registers
+    const int slot = m % NS;
+    const int cnt = m < K ? s_cnt[slot] : 0;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int p = tid + i * NTHR;
+      gs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p < cnt * PPR) gs[i] = src4[(size_t)s_src[slot][p / PPR] * PPR + (p % PPR)];
+    }
+  };
+  auto gather_commit = [&](int m, const f32x4* gs) { // registers -> shared tile
+    const int cnt = m < K ? s_cnt[m % NS] : 0;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int p = tid + i * NTHR;
+      if (p < cnt * PPR) *reinterpret_cast<f32x4*>(&s_a[(p / PPR) * LDA + (p % PPR) * 4]) = gs[i];
+    }
+  };
+  auto load_b = [&](int k, f32x4 (*b)[JG]) {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg)
+        b[t][jg] = k < K ? wp4[((size_t)(k * NT + nt0 + t) * JG + jg) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  f32x4 b_cur[NTW][JG], b_nx[NTW][JG];
+  gather_issue(0, g[0]);
+  gather_issue(1, g[1]);
+  gather_issue(2, g[2]);
+  load_b(0, b_cur);
+  gather_commit(0, g[0]);
+  __syncthreads();
+
+  // one phase = one kernel offset.  J = k % LA selects the register set statically (the loop is unrolled by LA).
+  auto phase = [&](int k, auto jc) {
+    constexpr int J = decltype(jc)::value;
+    const int slot = k % NS;
+    const int n_k = s_cnt[slot];
+    gather_issue(k + LA, g[J]);          // set J held offset k (already in the tile): reuse it for offset k+LA
+    load_b(k + 1, b_nx);
+
+    const int nch = (n_k + 15) >> 4;
+    for (int ch = 0; ch < nch; ++ch) {
+      const int p = ch * 16 + r;
+      f32x4 a[JG];
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) {
+        a[jg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p < n_k) a[jg] = *reinterpret_cast<const f32x4*>(&s_a[p * LDA + q * (CS / 4) + 4 * jg]);
+      }
+      f32x4 c0[NTW], c1[NTW];   // two accumulation chains per tile (dependent-issue latency 40 > issue interval 32)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) c0[t] = c1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            if ((e & 1) == 0)
+              c0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jg][e], b_cur[t][jg][e], c0[t], 0, 0, 0);
+            else
+              c1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jg][e], b_cur[t][jg][e], c1[t], 0, 0, 0);
+          }
+      const int pbase = ch * 16 + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (pbase + e < n_k) {
+          const int dl = s_dst[slot][pbase + e];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[dl * LDC + 16 * t + r] += c0[t][e] + c1[t][e];
+        }
+      }
+    }
+    if (wave == 0) {             // list of offset k+LA+1 -> the slot offset k-1 used (free since the last barrier)
+      if (k + LA + 1 < K) build_list(id_a, (k + LA + 1) % NS);
+      id_a = id_b;
+      id_b = load_id(k + LA + 3);
+    }
+    __syncthreads();             // everyone is done reading the tile / s_dst[slot]
+    gather_commit(k + 1, g[(J + 1) % LA]);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) b_cur[t][jg] = b_nx[t][jg];
+    __syncthreads();             // tile of offset k+1 visible
+  };
+  for (int k = 0; k < K; k += LA) {
+    phase(k, std::integral_constant<int, 0>{});
+    if (k + 1 < K) phase(k + 1, std::integral_constant<int, 1>{});
+    if (k + 2 < K) phase(k + 2, std::integral_constant<int, 2>{});
+  }
+
+  // epilogue: 4 lanes per row, one float4 each per 16 columns
+  const int col4 = (lane & 3) * 4;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int colg = 16 * (nt0 + t) + col4;
+    f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + colg);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + colg);
+    for (int rr = lane >> 2; rr < R; rr += 16) {
+      const int64_t row = row0 + rr;
+      if (row >= nlive) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(acc + rr * LDC + 16 * t + col4);
+      if (scale || shift) v = v * sc + sh;
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dst + row * CD + colg) = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- VALU fallback (any channel counts)
 // thread = (row, cd); weights in plain [k][cs][cd] order.  Used for conv_input (c_src = 4 or 5) and
 // for channel counts the MFMA kernels do not tile.
@@ -317,6 +503,32 @@ static int launch_mfma(const float* src, const float* wp, const int32_t* pair, i
   {
     // The pair-compacting kernel wins only on low-density strided layers (measured); it is kept selectable for
     // experiments (SPX_CONV_CP=1) and is NOT the default.
+    int use_bc = 0;
+    if (const char* e = getenv("SPX_CONV_BC")) use_bc = atoi(e);  // dev override
+    if (use_bc && CD >= 32) {
+      constexpr int NTW = CD >= 128 ? 2 : 1;
+      constexpr int WPT = (CD / 16) / NTW;
+      // rows per block: 64 compacts better (fewer padded MFMA rows), 32 gives twice the blocks and half the LDS.  Pick
+      // the one with the smaller  (dispatch rounds) x (rows per block) / (compaction efficiency)  on this chip.
+      auto lds_bytes = [&](int R) { return 4 * (R * (CS + 4) + WPT * R * (16 * NTW + 4)) + 5 * 2 * 4 * R + 64; };
+      auto cost = [&](int R, double eff) {
+        int per_cu = 160 * 1024 / lds_bytes(R);
+        int by_waves = 32 / WPT;
+        if (per_cu > by_waves) per_cu = by_waves;
+        if (per_cu < 1) per_cu = 1;
+        int64_t tiles = (n + R - 1) / R, slots = 256 * (int64_t)per_cu;
+        return (double)((tiles + slots - 1) / slots) * R / eff;
+      };
+      int R = cost(32, 0.70) < cost(64, 0.80) ? 32 : 64;
+      if (const char* e = getenv("SPX_CONV_BC_R")) R = atoi(e);
+      if (R == 32)
+        hipLaunchKernelGGL((k_conv_mfma_bc<CS, CD, NTW, 32>), dim3((unsigned)((n + 31) / 32)), dim3(64 * WPT), 0, s, src, wp,
+                           pair, ld, K, flip, n, d_n, scale, shift, relu, dst);
+      else
+        hipLaunchKernelGGL((k_conv_mfma_bc<CS, CD, NTW, 64>), dim3((unsigned)((n + 63) / 64)), dim3(64 * WPT), 0, s, src, wp,
+                           pair, ld, K, flip, n, d_n, scale, shift, relu, dst);
+      return SPX_OK;
+    }
     int use_cp = 0;
     if (const char* e = getenv("SPX_CONV_CP")) use_cp = atoi(e);  // dev override
     if (use_cp) {

@@ -38,9 +38,45 @@ class AxisAlignedTargetAssigner(object):
             raise NotImplementedError("only the SECOND configuration (POS_FRACTION -1, MATCH_HEIGHT False, single "
                                       "head) is on the hot path")
 
+    def _kernel_inputs(self, all_anchors):
+        """Static device-side inputs of the fused HIP assigner (cached per device)."""
+        dev = all_anchors[0].device
+        cache = getattr(self, "_kcache", None)
+        if cache is None or cache[0] != dev:
+            shapes = {tuple(a.shape) for a in all_anchors}
+            ok = len(shapes) == 1 and all_anchors[0].shape[-1] == 7 and self.box_coder.code_size == 7
+            if ok:
+                flat = torch.stack([a.reshape(-1, 7) for a in all_anchors], 0).contiguous().float()
+                per_loc = all_anchors[0].shape[3] * all_anchors[0].shape[4]
+                set_cls = torch.tensor([self.class_names.index(n) for n in self.anchor_class_names], dtype=torch.int32,
+                                       device=dev)
+                mt = torch.tensor([self.matched_thresholds[n] for n in self.anchor_class_names], dtype=torch.float32,
+                                  device=dev)
+                um = torch.tensor([self.unmatched_thresholds[n] for n in self.anchor_class_names], dtype=torch.float32,
+                                  device=dev)
+                cache = (dev, (flat, per_loc, set_cls, mt, um))
+            else:
+                cache = (dev, None)
+            self._kcache = cache
+        return cache[1]
+
     def assign_targets(self, all_anchors, gt_boxes_with_classes):
         """all_anchors: per class [1, H, W, n_size, n_rot, 7]; gt (B, M, 8).  Returns box_cls_labels [B, A] int32,
-        box_reg_targets [B, A, code], reg_weights [B, A] with A ordered (y, x, class, size, rot)."""
+        box_reg_targets [B, A, code], reg_weights [B, A] with A ordered (y, x, class, size, rot).
+
+        On the GPU this is libspx's fused assigner (csrc/assign.hip, two launches); the batched torch formulation
+        below is the same rule and serves CPU tensors (tests) and anchor layouts the kernel does not cover."""
+        gt = gt_boxes_with_classes
+        if gt.is_cuda and gt.shape[-1] == 8 and gt.shape[1] <= 256:
+            kin = self._kernel_inputs(all_anchors)
+            if kin is not None:
+                from spx import ops
+                flat, per_loc, set_cls, mt, um = kin
+                labels, targets, weights = ops.assign_targets(flat, per_loc, gt, set_cls, len(self.class_names), mt, um)
+                return {'box_cls_labels': labels, 'box_reg_targets': targets, 'reg_weights': weights}
+        return self.assign_targets_torch(all_anchors, gt)
+
+    def assign_targets_torch(self, all_anchors, gt_boxes_with_classes):
         gt = gt_boxes_with_classes
         B, M = gt.shape[0], gt.shape[1]
         dev = gt.device

@@ -46,6 +46,9 @@ SIGNATURES = {
     "spx_boxes_iou_bev": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp]),
     "spx_nms_ws_bytes": (_sz, [_i64]),
     "spx_nms_bev": (_int, [_vp, _i64, ctypes.c_float, _int, _vp, _vp, _vp, _sz, _vp]),
+    "spx_assign_targets_ws_bytes": (_sz, [_int, _int, _int]),
+    "spx_assign_targets": (_int, [_vp, _int, _i64, _int, _vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                  _vp]),
 }
 
 _lib = None

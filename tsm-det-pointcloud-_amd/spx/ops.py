@@ -260,3 +260,26 @@ def nms_bev(boxes_sorted, thresh, axis_aligned=False):
     check(lib.spx_nms_bev(_ptr(b), n, float(thresh), int(bool(axis_aligned)), _ptr(keep), _ptr(cnt), _ptr(ws), wsb,
                           _stream(b)), "spx_nms_bev")
     return keep, cnt
+
+
+# ------------------------------------------------------------------------------------------- anchor target assignment
+
+def assign_targets(anchors, per_location, gt_boxes, set_class, n_classes, matched, unmatched):
+    """anchors [n_sets, A, 7] fp32, gt_boxes [B, M, 8] fp32, set_class int32[n_sets], matched/unmatched fp32[n_sets]
+    (all on the GPU) -> labels int32 [B, n_sets*A], targets fp32 [B, n_sets*A, 7], weights fp32 [B, n_sets*A]
+    in the head's (y, x, set, within-location) anchor order.  No host sync."""
+    _need_gpu(anchors, gt_boxes, set_class, matched, unmatched)
+    lib = _lib.load()
+    n_sets, a, _ = anchors.shape
+    gt = gt_boxes.contiguous().float()
+    b, m = gt.shape[0], gt.shape[1]
+    dev = gt.device
+    labels = torch.empty((b, n_sets * a), dtype=torch.int32, device=dev)
+    targets = torch.empty((b, n_sets * a, 7), dtype=torch.float32, device=dev)
+    weights = torch.empty((b, n_sets * a), dtype=torch.float32, device=dev)
+    wsb = lib.spx_assign_targets_ws_bytes(b, n_sets, m)
+    ws = workspace(dev, wsb)
+    check(lib.spx_assign_targets(_ptr(anchors), n_sets, a, int(per_location), _ptr(gt), b, m, _ptr(set_class),
+                                 int(n_classes), _ptr(matched), _ptr(unmatched), _ptr(labels), _ptr(targets),
+                                 _ptr(weights), _ptr(ws), wsb, _stream(gt)), "spx_assign_targets")
+    return labels, targets, weights
