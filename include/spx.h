@@ -208,6 +208,24 @@ int spx_assign_targets(const float *anchors, int n_sets, int64_t anchors_per_set
                        const float *d_matched, const float *d_unmatched, int32_t *labels, float *targets,
                        float *weights, void *ws, size_t ws_bytes, spx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * 8. Anchor-head losses, forward + gradient in one pass (training)
+ *    replaces: AnchorHeadTemplate.get_cls_layer_loss / get_box_reg_layer_loss and their autograd, reference
+ *      pcdet/models/dense_heads/anchor_head_template.py:101-224 with the loss classes of
+ *      pcdet/utils/loss_utils.py:9-77 (sigmoid focal, alpha/gamma=2), :140-209 (smooth L1, beta, unit code weights,
+ *      after add_sin_difference) and :310-338 (weighted cross entropy on direction bins).
+ *    cls_preds [batch][A][num_class], box_preds [batch][A][7], dir_preds [batch][A][num_dir_bins] (NULL: no direction
+ *    classifier), labels int32 [batch][A], reg_targets [batch][A][7], anchors [A][7] — all device, anchor order of the head.
+ *    losses  device fp32[3] = (cls, loc, dir), each already divided by batch and multiplied by its weight
+ *    dcls/dbox/ddir  device, same shapes as the predictions: d(weighted loss)/d(prediction)
+ * ---------------------------------------------------------------------------------------------- */
+size_t spx_anchor_loss_ws_bytes(int batch, int64_t n_anchors);
+int spx_anchor_loss(const float *cls_preds, const float *box_preds, const float *dir_preds, const int32_t *labels,
+                    const float *reg_targets, const float *anchors, int batch, int64_t n_anchors, int num_class,
+                    int num_dir_bins, float dir_offset, float cls_weight, float loc_weight, float dir_weight,
+                    float beta, float alpha, float *losses, float *dcls, float *dbox, float *ddir, void *ws,
+                    size_t ws_bytes, spx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -280,3 +280,31 @@ def test_fused_target_assigner_matches_torch_formulation(cfg_id, batch):
     assert float((got["box_reg_targets"] - ref["box_reg_targets"]).abs().max()) < 1e-5
     assert int((ref["box_cls_labels"] > 0).sum()) > 0 and int((ref["box_cls_labels"] < 0).sum()) > 0
     assert int((ref["box_cls_labels"][-1] != 0).sum()) == 0
+
+
+def test_fused_anchor_loss_matches_torch_formulation():
+    """csrc/anchor_loss.hip (loss values + gradients in one pass) against the torch restatement of
+    anchor_head_template.py:101-224 (itself pinned to the reference by tests/test_ref_modules.py)."""
+    from pcdet_amd.datasets import synthetic
+    _cfg, ds, model = _build(cfg_id=2)
+    dev = torch.device("cuda:0")
+    head = model.dense_head.to(dev).train()
+    g = torch.Generator().manual_seed(2)
+    gt = torch.from_numpy(synthetic.make_batch(2, 3)["gt_boxes"]).to(dev)
+    feat = (torch.randn(3, 512, 200, 176, generator=g) * 0.5).to(dev)
+    grads = []
+    vals = []
+    for fused in (True, False):
+        x = feat.clone().requires_grad_(True)
+        head.zero_grad()
+        head({"spatial_features_2d": x, "gt_boxes": gt, "batch_size": 3})
+        loss, tb = head.get_loss_fused() if fused else head.get_loss_torch()
+        loss.backward()
+        vals.append([float(loss), float(tb["rpn_loss_cls"]), float(tb["rpn_loss_loc"]), float(tb["rpn_loss_dir"])])
+        grads.append([x.grad.clone(), head.conv_cls.weight.grad.clone(), head.conv_box.weight.grad.clone(),
+                      head.conv_dir_cls.weight.grad.clone()])
+    assert head._fused_loss_ok()
+    for a, b in zip(*vals):
+        assert abs(a - b) < 2e-5 * max(1.0, abs(b)), (vals)
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) < 2e-5 * float(b.abs().max()), (float((a - b).abs().max()), float(b.abs().max()))

@@ -10,6 +10,29 @@ from .target_assigner.anchor_generator import AnchorGenerator
 from .target_assigner.axis_aligned_target_assigner import AxisAlignedTargetAssigner
 
 
+class _FusedAnchorLoss(torch.autograd.Function):
+    """losses[3] = (cls, loc, dir), each already weighted and divided by the batch size; one libspx launch group computes
+    them together with d(loss)/d(prediction) (csrc/anchor_loss.hip), backward only scales the saved gradients."""
+
+    @staticmethod
+    def forward(ctx, cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, consts):
+        from spx import ops
+        dir_offset, cls_w, loc_w, dir_w, beta, alpha = consts
+        losses, dcls, dbox, ddir = ops.anchor_loss(cls_preds, box_preds, dir_preds, labels, reg_targets, anchors,
+                                                   dir_offset, cls_w, loc_w, dir_w, beta, alpha)
+        ctx.has_dir = ddir is not None
+        ctx.save_for_backward(dcls, dbox, ddir if ddir is not None else dcls.new_empty(0))
+        ctx.shapes = (cls_preds.shape, box_preds.shape, None if dir_preds is None else dir_preds.shape)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        dcls, dbox, ddir = ctx.saved_tensors
+        sc, sb, sd = ctx.shapes
+        return ((dcls * g[0]).view(sc), (dbox * g[1]).view(sb), (ddir * g[2]).view(sd) if ctx.has_dir else None,
+                None, None, None, None)
+
+
 class AnchorHeadTemplate(nn.Module):
     def __init__(self, model_cfg, num_class, class_names, grid_size, point_cloud_range, predict_boxes_when_training):
         super().__init__()
@@ -139,7 +162,44 @@ class AnchorHeadTemplate(nn.Module):
             tb_dict['rpn_loss_dir'] = dir_loss.detach()
         return box_loss, tb_dict
 
+    def _fused_loss_ok(self):
+        fr = self.forward_ret_dict
+        rl = self.reg_loss_func
+        return (fr['cls_preds'].is_cuda and type(rl) is loss_utils.WeightedSmoothL1Loss and self.num_class <= 8
+                and fr['box_cls_labels'].dtype == torch.int32 and self.box_coder.code_size == 7
+                and (rl.code_weights is None or bool((rl.code_weights == 1).all()))
+                and not self.use_multihead and self.num_class > 1)
+
+    def get_loss_fused(self):
+        """Same three losses as get_cls_layer_loss + get_box_reg_layer_loss, computed (with their gradients) by libspx."""
+        fr = self.forward_ret_dict
+        cls_preds, box_preds = fr['cls_preds'], fr['box_preds']
+        dir_preds = fr.get('dir_cls_preds', None)
+        b = int(cls_preds.shape[0])
+        anchors = self._flat_anchors().reshape(-1, 7)
+        a = anchors.shape[0]
+        w = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        consts = (float(self.model_cfg.get('DIR_OFFSET', 0.0)), float(w['cls_weight']), float(w['loc_weight']),
+                  float(w.get('dir_weight', 0.0)), float(self.reg_loss_func.beta), float(self.cls_loss_func.alpha))
+        assert self.cls_loss_func.gamma == 2.0
+        losses = _FusedAnchorLoss.apply(cls_preds.view(b, a, self.num_class), box_preds.view(b, a, 7),
+                                        None if dir_preds is None else dir_preds.view(b, a, -1), fr['box_cls_labels'],
+                                        fr['box_reg_targets'], anchors, consts)
+        tb_dict = {'rpn_loss_cls': losses[0].detach(), 'rpn_loss_loc': losses[1].detach()}
+        if dir_preds is not None:
+            tb_dict['rpn_loss_dir'] = losses[2].detach()
+            rpn_loss = losses.sum()
+        else:
+            rpn_loss = losses[0] + losses[1]
+        tb_dict['rpn_loss'] = rpn_loss.detach()
+        return rpn_loss, tb_dict
+
     def get_loss(self):
+        if self._fused_loss_ok():
+            return self.get_loss_fused()
+        return self.get_loss_torch()
+
+    def get_loss_torch(self):
         cls_loss, tb_dict = self.get_cls_layer_loss()
         box_loss, tb_box = self.get_box_reg_layer_loss()
         tb_dict.update(tb_box)

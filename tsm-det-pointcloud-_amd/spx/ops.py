@@ -283,3 +283,31 @@ def assign_targets(anchors, per_location, gt_boxes, set_class, n_classes, matche
                                  int(n_classes), _ptr(matched), _ptr(unmatched), _ptr(labels), _ptr(targets),
                                  _ptr(weights), _ptr(ws), wsb, _stream(gt)), "spx_assign_targets")
     return labels, targets, weights
+
+
+# ------------------------------------------------------------------------------------------- anchor-head losses
+
+def anchor_loss(cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, dir_offset, cls_weight, loc_weight,
+                dir_weight, beta=1.0 / 9.0, alpha=0.25):
+    """cls_preds [B,A,NC], box_preds [B,A,7], dir_preds [B,A,NB] or None, labels int32 [B,A], reg_targets [B,A,7],
+    anchors [A,7] -> (losses fp32[3] = weighted cls/loc/dir, dcls, dbox, ddir).  No host sync."""
+    _need_gpu(cls_preds, box_preds, labels, reg_targets, anchors)
+    lib = _lib.load()
+    cls_preds, box_preds = cls_preds.contiguous().float(), box_preds.contiguous().float()
+    dir_c = None if dir_preds is None else dir_preds.contiguous().float()
+    labels = labels.contiguous()
+    assert labels.dtype == torch.int32
+    reg_targets, anchors = reg_targets.contiguous().float(), anchors.contiguous().float()
+    b, a, nc = cls_preds.shape
+    nb = 0 if dir_c is None else dir_c.shape[2]
+    dev = cls_preds.device
+    losses = torch.zeros((3,), dtype=torch.float32, device=dev)
+    dcls, dbox = torch.empty_like(cls_preds), torch.empty_like(box_preds)
+    ddir = None if dir_c is None else torch.empty_like(dir_c)
+    wsb = lib.spx_anchor_loss_ws_bytes(b, a)
+    ws = workspace(dev, wsb)
+    check(lib.spx_anchor_loss(_ptr(cls_preds), _ptr(box_preds), _ptr(dir_c), _ptr(labels), _ptr(reg_targets),
+                              _ptr(anchors), b, a, nc, nb, float(dir_offset), float(cls_weight), float(loc_weight),
+                              float(dir_weight), float(beta), float(alpha), _ptr(losses), _ptr(dcls), _ptr(dbox),
+                              _ptr(ddir), _ptr(ws), wsb, _stream(cls_preds)), "spx_anchor_loss")
+    return losses, dcls, dbox, ddir
