@@ -47,10 +47,15 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU (default: the config's)")
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
     ap.add_argument("--dense-dtype", default="f32", choices=["f32", "bf16", "f16"])
+    ap.add_argument("--dense-layout", default="nhwc", choices=["nhwc", "nchw"], help="memory format of the BEV backbone")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen find mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     return ap.parse_args()
+
+
+DENSE_LAYOUT = "nhwc"
 
 
 def build(cfg_id, device, dense_dtype):
@@ -66,8 +71,10 @@ def build(cfg_id, device, dense_dtype):
     torch.manual_seed(0)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
     model.to(device)
-    if dense_dtype != "f32" or device.type == "cuda":
+    if device.type == "cuda" and DENSE_LAYOUT == "nhwc":
         model.backbone_2d.to(memory_format=torch.channels_last)
+    if device.type == "cuda":
+        model.map_to_bev_module.channels_last = DENSE_LAYOUT == "nhwc"
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
     sched, _ = build_scheduler(optimizer, 1000, 80, -1, cfg.OPTIMIZATION)
     return cfg, ds, model, optimizer, sched
@@ -310,6 +317,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
     from pcdet_amd.datasets import synthetic
+    global DENSE_LAYOUT
+    DENSE_LAYOUT = args.dense_layout
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     batch = args.batch or synthetic.CONFIGS[args.cfg]["batch"]
     cfg, ds, model, optimizer, sched = build(args.cfg, device, args.dense_dtype)
     model.train(args.mode == "train")
