@@ -72,3 +72,31 @@ def test_reference_voxelbackbone8x_runs_on_spx():
     assert torch.equal(out_t["spatial_features"], out_o["spatial_features"])
     assert out_t["spatial_features"].shape == (2, 256, 40, 32)
     assert out_t["encoded_spconv_tensor_stride"] == 8
+
+
+def test_reference_voxelresbackbone8x_runs_on_spx():
+    """Row f-3: the reference's residual backbone (SparseBasicBlock, bias=True convs, 128-wide stage) on our operators."""
+    from oracle.cpu_backend import use_oracle_backend
+    from pcdet_amd.config import AttrDict
+    from pcdet_amd.datasets import SyntheticDataset
+    from pcdet_amd.models.backbones_3d import VoxelResBackBone8x
+    ref_bb, _ = _import_reference_backbone()
+    ds = SyntheticDataset(cfg_id=0)
+    torch.manual_seed(1)
+    ours = VoxelResBackBone8x(AttrDict(), 4, ds.grid_size)
+    theirs = ref_bb.VoxelResBackBone8x(AttrDict(), 4, ds.grid_size)
+    assert list(theirs.state_dict().keys()) == list(ours.state_dict().keys())
+    theirs.load_state_dict(ours.state_dict())
+    ours.eval()
+    theirs.eval()
+    b = ds.collate_batch([ds[0]])
+    with torch.no_grad(), use_oracle_backend():
+        from spx import ops
+        vox = ops.voxelize(torch.from_numpy(b["points"]), ds.point_cloud_range, ds.voxel_size, 5, 16000, batch_size=1,
+                           batch_col=0, xyz_col=1, feat_col=1, want_voxels=False)
+        bd = {"voxel_features": vox["mean"], "voxel_coords": vox["coords"].float(), "batch_size": 1}
+        o, t = ours(dict(bd)), theirs(dict(bd))
+    for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        assert torch.equal(t["multi_scale_3d_features"][k].features, o["multi_scale_3d_features"][k].features)
+    assert torch.equal(t["encoded_spconv_tensor"].features, o["encoded_spconv_tensor"].features)
+    assert o["encoded_spconv_tensor"].features.shape[1] == 128

@@ -31,6 +31,89 @@ def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stri
     return spconv.SparseSequential(*layers)
 
 
+class SparseBasicBlock(spconv.SparseModule):
+    """Residual block of two submanifold convs sharing one rulebook (reference spconv_backbone.py:38-74; SURVEY §8 row
+    f-3).  bias=True on both convs, BN after each, identity (or `downsample`) added before the last ReLU."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, norm_fn=None, downsample=None, indice_key=None):
+        super().__init__()
+        assert norm_fn is not None
+        self.conv1 = spconv.SubMConv3d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=True,
+                                       indice_key=indice_key)
+        self.bn1 = norm_fn(planes)
+        self.relu = nn.ReLU()
+        self.conv2 = spconv.SubMConv3d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=True,
+                                       indice_key=indice_key)
+        self.bn2 = norm_fn(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.conv1(x)
+        out = out.replace_feature(self.relu(self.bn1(out.features)))
+        out = self.conv2(out)
+        out = out.replace_feature(self.relu(self.bn2(out.features) + identity.features))
+        return out
+
+
+def _run_8x_stack(self, batch_dict, with_points_keys):
+    voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
+    x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(), spatial_shape=self.sparse_shape,
+                                batch_size=batch_dict['batch_size'])
+    x = self.conv_input(x)
+    x_conv1 = self.conv1(x)
+    x_conv2 = self.conv2(x_conv1)
+    x_conv3 = self.conv3(x_conv2)
+    x_conv4 = self.conv4(x_conv3)
+    out = self.conv_out(x_conv4)
+    batch_dict['encoded_spconv_tensor'] = out
+    batch_dict['encoded_spconv_tensor_stride'] = 8
+    feats = {'x_conv1': x_conv1, 'x_conv2': x_conv2, 'x_conv3': x_conv3, 'x_conv4': x_conv4}
+    strides = {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}
+    if with_points_keys:
+        feats.update({'x_points_mean': x_conv2, 'x_points_max': x_conv2})
+        strides.update({'x_points_mean': 2, 'x_points_max': 2})
+    batch_dict['multi_scale_3d_features'] = feats
+    batch_dict['multi_scale_3d_strides'] = strides
+    return batch_dict
+
+
+class VoxelResBackBone8x(nn.Module):
+    """Residual variant (reference spconv_backbone.py:197-307): same stage layout, SparseBasicBlock pairs, 128-wide
+    stage 4.  Same kernels as VoxelBackBone8x; parameter names follow the reference (`conv1.0.conv1.weight`, ...)."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.sparse_shape = [int(grid_size[2]) + 1, int(grid_size[1]), int(grid_size[0])]
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key='subm1'), norm_fn(16), nn.ReLU())
+        block = partial(post_act_block, norm_fn=norm_fn)
+        res = partial(SparseBasicBlock, norm_fn=norm_fn)
+        self.conv1 = spconv.SparseSequential(res(16, 16, indice_key='res1'), res(16, 16, indice_key='res1'))
+        self.conv2 = spconv.SparseSequential(
+            block(16, 32, 3, stride=2, padding=1, indice_key='spconv2', conv_type='spconv'),
+            res(32, 32, indice_key='res2'), res(32, 32, indice_key='res2'))
+        self.conv3 = spconv.SparseSequential(
+            block(32, 64, 3, stride=2, padding=1, indice_key='spconv3', conv_type='spconv'),
+            res(64, 64, indice_key='res3'), res(64, 64, indice_key='res3'))
+        self.conv4 = spconv.SparseSequential(
+            block(64, 128, 3, stride=2, padding=(0, 1, 1), indice_key='spconv4', conv_type='spconv'),
+            res(128, 128, indice_key='res4'), res(128, 128, indice_key='res4'))
+        last_pad = self.model_cfg.get('last_pad', 0) if hasattr(self.model_cfg, 'get') else 0
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(128, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                indice_key='spconv_down2'), norm_fn(128), nn.ReLU())
+        self.num_point_features = 128
+        self.backbone_channels = {'x_conv1': 16, 'x_conv2': 32, 'x_conv3': 64, 'x_conv4': 128}
+
+    def forward(self, batch_dict):
+        return _run_8x_stack(self, batch_dict, with_points_keys=False)
+
+
 class VoxelBackBone8x(nn.Module):
     def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
         super().__init__()
