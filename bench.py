@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cfg", type=int, default=2, help="synthetic config id (BASELINE.md §4); 2 = KITTI batch 4")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU (default: the config's)")
-    ap.add_argument("--mode", default="train", choices=["train", "fwd"])
+    ap.add_argument("--mode", default="train", choices=["train", "fwd", "fwd-graph"],
+                    help="fwd-graph: sync-free forward captured in one hipGraph (pcdet_amd/models/inference.py)")
     ap.add_argument("--dense-dtype", default="f32", choices=["f32", "bf16", "f16"])
     ap.add_argument("--dense-layout", default="nhwc", choices=["nhwc", "nchw"], help="memory format of the BEV backbone")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen find mode)")
@@ -107,6 +108,12 @@ class Step(object):
 
     def __call__(self, batch):
         bd = dict(batch)
+        if self.mode == "fwd-graph":
+            if getattr(self, "runner", None) is None:
+                from pcdet_amd.models.inference import GraphedDetector
+                core = self.model.module if hasattr(self.model, "module") else self.model
+                self.runner = GraphedDetector(core, batch["batch_size"], int(batch["points"].shape[0] * 1.05) + 64)
+            return self.runner(batch["points"])["batch_box_preds"]
         if self.mode == "fwd":
             with torch.no_grad():
                 for m in (self.model.module if hasattr(self.model, "module") else self.model).module_list:
@@ -156,14 +163,15 @@ class KernelTimer(object):
         self._saved = {n: getattr(ops, n) for n in names}
         sv = self._saved
 
-        def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False):
+        def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False,
+                      d_n_dst=None):
             cs = src.shape[1]
             P = t._P(pair, n_dst)
             flops = 2.0 * P * cs * c_dst
             nbytes = 4.0 * (src.shape[0] * cs + n_dst * c_dst + kvol * cs * c_dst + kvol * n_dst)
             fam = "conv_gemm[mfma]" if (cs % 16 == 0 and c_dst % 16 == 0) else "conv_gemm[valu]"
             return t._timed(fam, flops, nbytes, sv["conv_gemm"], src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k,
-                            scale, shift, relu)
+                            scale, shift, relu, d_n_dst)
 
         def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
             cout, cin = wshape[0], wshape[-1]
@@ -173,17 +181,17 @@ class KernelTimer(object):
             nbytes = 4.0 * (feat_in.shape[0] * cin + n_out * cout + K * n_out + K * cin * cout)
             return t._timed("conv_wgrad", flops, nbytes, sv["conv_wgrad"], feat_in, dout, pair, ld, n_out, wshape)
 
-        def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False):
+        def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None):
             n = indices.shape[0]
             K = int(np.prod(ksize))
             return t._timed("subm_rulebook", 0.0, n * 16.0 + K * n * 4.0, sv["subm_rulebook"], indices, batch_size,
-                            spatial_shape, ksize, dilation, want_cnt)
+                            spatial_shape, ksize, dilation, want_cnt, d_n)
 
         def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1),
-                          want_cnt=False):
+                          want_cnt=False, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rb = sv["conv_rulebook"](indices, batch_size, spatial_shape, ksize, stride, padding, dilation, want_cnt)
+            rb = sv["conv_rulebook"](indices, batch_size, spatial_shape, ksize, stride, padding, dilation, want_cnt, **kw)
             e1.record()
             n, K = indices.shape[0], int(np.prod(ksize))
             t.rec.append(("conv_rulebook", 0.0, n * 16.0 + K * rb.n_out * 4.0 + K * n * 4.0 + rb.n_out * 16.0, e0, e1))
@@ -198,11 +206,11 @@ class KernelTimer(object):
             t.rec.append(("voxelize+meanvfe", 0.0, 4.0 * points.shape[0] * c + 4.0 * out["num_voxels"] * (c + 4), e0, e1))
             return out
 
-        def densify(features, indices, batch_size, spatial_shape, channels_last=False):
+        def densify(features, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
             n, c = features.shape
             cells = batch_size * int(np.prod(spatial_shape))
             return t._timed("densify(+memset)", 0.0, 4.0 * (n * c + c * cells), sv["densify"], features, indices,
-                            batch_size, spatial_shape, channels_last)
+                            batch_size, spatial_shape, channels_last, d_n)
 
         def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False):
             n, c = indices.shape[0], ddense.shape[1]
@@ -352,7 +360,7 @@ def main():
     if rank == 0:
         geom = synthetic.CONFIGS[args.cfg]
         line = {
-            "metric": "point-cloud frames/sec (%s)" % ("fwd+bwd" if args.mode == "train" else "fwd"),
+            "metric": "point-cloud frames/sec (%s)" % ("fwd+bwd" if args.mode == "train" else args.mode),
             "value": round(world * batch * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -116,7 +116,9 @@ int spx_subm_rulebook(const int32_t *idx, int64_t n, const int64_t *d_n, int bat
  *      pair_fwd   device [K, cap]  int32 : pair_fwd[k*cap + o] = input row feeding output o at offset k, or -1
  *      pair_bwd   device [K, n_in] int32 : pair_bwd[k*n_in + i] = output row fed by input i at offset k, or -1
  *      cnt        device int32[K] (nullable);  d_n_out device int64[1] = number of active outputs
- *      cap        output-row capacity, >= min(prod(ceil(k/s)) * n_in, batch*out cells)  (spx_conv_out_cap)
+ *      cap        output-row capacity.  spx_conv_out_cap() = min(prod(ceil(k/s)) * n_in, batch*out cells) can never
+ *                 overflow; a smaller static capacity is allowed (graph mode): rows beyond cap are dropped and
+ *                 *d_n_out still reports the true count, so *d_n_out > cap signals overflow
  * ---------------------------------------------------------------------------------------------- */
 int64_t spx_conv_out_cap(int64_t n_in, int batch, const int32_t *out_shape, const int32_t *ksize,
                          const int32_t *stride);

@@ -26,7 +26,7 @@ def _np(t):
 
 
 def voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels, batch_size=1, batch_col=-1, xyz_col=0,
-             feat_col=0, num_features=None, want_voxels=True, want_mean=True):
+             feat_col=0, num_features=None, want_voxels=True, want_mean=True, sync=True):
     pts = np.ascontiguousarray(_np(points), np.float32)
     c = (pts.shape[1] - feat_col) if num_features is None else int(num_features)
     vs, cs, ns = [], [], []
@@ -42,7 +42,7 @@ def voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels, batc
     grid = [int(round((rng[3 + j] - rng[j]) / float(voxel_size[j]))) for j in range(3)]
     return dict(voxels=torch.from_numpy(v) if want_voxels else None, coords=torch.from_numpy(co),
                 num_points=torch.from_numpy(n), mean=torch.from_numpy(orc.mean_vfe(v, n)) if want_mean else None,
-                num_voxels=v.shape[0], grid_size=grid)
+                num_voxels=v.shape[0], d_num_voxels=None, grid_size=grid)
 
 
 def mean_vfe(voxels, num_points):
@@ -54,7 +54,7 @@ def _rulebook_cls():
     return Rulebook
 
 
-def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False):
+def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None):
     pair, cnt = orc.subm_rulebook(_np(indices), spatial_shape, ksize, dilation)
     n = indices.shape[0]
     pair_t = torch.from_numpy(np.ascontiguousarray(pair)) if n else torch.zeros((pair.shape[0], 1), dtype=torch.int32)
@@ -63,7 +63,8 @@ def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1),
                            padding=[k // 2 for k in ksize], dilation=list(dilation))
 
 
-def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1), want_cnt=False):
+def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1), want_cnt=False,
+                  d_n_in=None, cap=None, sync=True):
     oi, pf, pb, cnt, oshape = orc.conv_rulebook(_np(indices), spatial_shape, ksize, stride, padding, dilation)
     n_in, n_out = indices.shape[0], oi.shape[0]
     return _rulebook_cls()(torch.from_numpy(np.ascontiguousarray(pf)), max(n_out, 1), n_in, n_out, pf.shape[0], False,
@@ -76,7 +77,8 @@ def pack_weight(weight, mode):
     return _PackedW(weight, mode)
 
 
-def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False):
+def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False,
+              d_n_dst=None):
     x = _np(src).astype(np.float32)
     p = _np(pair)[:, :n_dst]
     w = w_packed.w  # [Cout, K, Cin]
@@ -111,7 +113,7 @@ def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
     return torch.from_numpy(dw.reshape(tuple(wshape)))
 
 
-def densify(features, indices, batch_size, spatial_shape, channels_last=False):
+def densify(features, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
     return torch.from_numpy(orc.densify(_np(features), _np(indices), batch_size, [int(s) for s in spatial_shape]))
 
 

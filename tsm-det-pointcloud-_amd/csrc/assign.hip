@@ -183,7 +183,7 @@ extern "C" int spx_assign_targets(const float* anchors, int n_sets, int64_t anch
   g.B = batch;
   g.M = max_gt;
   g.A = anchors_per_set;
-  (void)hipMemsetAsync(gmax, 0, (size_t)batch * n_sets * max_gt * 4, s);
+  spx_fill_async(gmax, 0, (size_t)batch * n_sets * max_gt * 4, s);
   hipLaunchKernelGGL(k_gt_keep, dim3((batch + 63) / 64), dim3(64), 0, s, g, nkeep);
   dim3 grid((unsigned)((anchors_per_set + 255) / 256), n_sets, batch);
   hipLaunchKernelGGL(k_gt_max, grid, dim3(256), 0, s, g, nkeep, gmax);

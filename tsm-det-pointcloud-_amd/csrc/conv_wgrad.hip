@@ -166,7 +166,7 @@ extern "C" int spx_conv_wgrad(const float* in, int cin, const float* dout, int c
   if (!ws || ws_bytes < spx_conv_wgrad_ws_bytes(cin, cout, kvol, n_out)) return SPX_ERR_WORKSPACE;
   hipStream_t s = spx_s(stream);
   if (n_out == 0) {
-    (void)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cout * kvol * cin, s);
+    spx_fill_async(dw, 0, sizeof(float) * (size_t)cout * kvol * cin, s);
     return SPX_OK;
   }
   int S = wgrad_splits(n_out, cin, cout, kvol);

@@ -231,7 +231,7 @@ extern "C" int spx_nms_bev(const float* boxes, int64_t n, float thresh, int axis
   if (n > (int64_t(1) << 20)) return SPX_ERR_TOO_LARGE;   // removed-mask must fit LDS: 2^20 / 64 words = 128 KiB
   hipStream_t s = spx_s(stream);
   if (n == 0) {
-    (void)hipMemsetAsync(d_num_keep, 0, sizeof(int64_t), s);
+    spx_fill_async(d_num_keep, 0, sizeof(int64_t), s);
     return SPX_OK;
   }
   if (!ws || ws_bytes < spx_nms_ws_bytes(n)) return SPX_ERR_WORKSPACE;

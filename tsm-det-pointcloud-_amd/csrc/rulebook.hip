@@ -285,15 +285,15 @@ extern "C" int spx_subm_rulebook(const int32_t* idx, int64_t n, const int64_t* d
   if (n >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
   if (!ws || ws_bytes < spx_subm_rulebook_ws_bytes(n)) return SPX_ERR_WORKSPACE;
   hipStream_t s = spx_s(stream);
-  if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * K, s);
+  if (cnt) spx_fill_async(cnt, 0, sizeof(int32_t) * K, s);
   if (n == 0) return SPX_OK;
   int64_t slots = hash_slots(n);
   HashTable t;
   t.keys = reinterpret_cast<uint64_t*>(ws);
   t.vals = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + spx_align((size_t)slots * 8));
   t.log2size = ilog2(slots);
-  (void)hipMemsetAsync(t.keys, 0xFF, (size_t)slots * 8, s);
-  (void)hipMemsetAsync(t.vals, 0x7F, (size_t)slots * 4, s);
+  spx_fill_async(t.keys, 0xFF, (size_t)slots * 8, s);
+  spx_fill_async(t.vals, 0x7F, (size_t)slots * 4, s);
   unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_hash_insert, dim3(nb), dim3(kBlock), 0, s, idx, n, d_n, batch, spx_i3(shape), t);
   hipLaunchKernelGGL(k_subm_probe, dim3(nb, K), dim3(kBlock), 0, s, idx, n, d_n, spx_i3(shape), spx_i3(ksize),
@@ -359,7 +359,8 @@ extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t
   }
   if (n_in >= (int64_t(1) << 31) || cap >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
   if (cells_of(batch, out_shape) >= (int64_t(1) << 40)) return SPX_ERR_TOO_LARGE;
-  if (cap < spx_conv_out_cap(n_in, batch, out_shape, ksize, stride)) return SPX_ERR_INVALID_ARG;
+  // cap below spx_conv_out_cap() is allowed (static-capacity / graph mode): rows beyond cap are dropped and the true
+  // count still lands in *d_n_out, so the caller detects overflow as *d_n_out > cap.
   if (!ws || ws_bytes < spx_conv_rulebook_ws_bytes(n_in, batch, out_shape)) return SPX_ERR_WORKSPACE;
   hipStream_t s = spx_s(stream);
   RbWs w = rb_layout(ws, batch, out_shape);
@@ -370,8 +371,8 @@ extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t
   g.stride = spx_i3(stride);
   g.pad = spx_i3(pad);
   g.dil = spx_i3(dil);
-  if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int32_t) * K, s);
-  (void)hipMemsetAsync(w.bits, 0, (size_t)w.nwords * 8, s);
+  if (cnt) spx_fill_async(cnt, 0, sizeof(int32_t) * K, s);
+  spx_fill_async(w.bits, 0, (size_t)w.nwords * 8, s);
   unsigned nb_in = (unsigned)((n_in + kBlock - 1) / kBlock);
   if (n_in > 0) hipLaunchKernelGGL(k_mark, dim3(nb_in, K), dim3(kBlock), 0, s, idx, n_in, d_n_in, batch, g, w.bits);
   hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum);

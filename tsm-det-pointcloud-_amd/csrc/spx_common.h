@@ -42,3 +42,22 @@ __device__ __forceinline__ int64_t spx_lin_key(int b, int z, int y, int x, const
 }
 
 __device__ __forceinline__ int spx_lane() { return threadIdx.x & 63; }
+
+// Device-side fill used instead of hipMemsetAsync: byte-pattern memset NODES of a captured hipGraph did not re-initialise
+// the workspace on the second replay (ROCm 7.x, observed as an endless CAS probe in the voxeliser's hash), whereas kernel
+// nodes replay correctly.  `bytes` must be a multiple of 4 (every buffer of this library is).
+static __global__ void spx_k_fill32(uint32_t* __restrict__ p, uint32_t v, size_t nwords) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < nwords; i += stride) p[i] = v;
+}
+
+static inline void spx_fill_async(void* ptr, int byte_value, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return;
+  const uint32_t b = (uint32_t)(byte_value & 0xFF);
+  const uint32_t v = b | (b << 8) | (b << 16) | (b << 24);
+  const size_t nwords = bytes / 4;
+  size_t nb = (nwords + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(spx_k_fill32, dim3((unsigned)nb), dim3(256), 0, s, reinterpret_cast<uint32_t*>(ptr), v, nwords);
+}

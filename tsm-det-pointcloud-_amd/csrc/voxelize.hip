@@ -258,7 +258,7 @@ extern "C" int spx_voxelize(const float* points, int64_t n_points, int point_str
   if (!ws || ws_bytes < spx_voxelize_ws_bytes(n_points, batch, max_points)) return SPX_ERR_WORKSPACE;
   hipStream_t s = spx_s(stream);
   if (n_points == 0) {
-    (void)hipMemsetAsync(d_num_voxels, 0, sizeof(int64_t), s);
+    spx_fill_async(d_num_voxels, 0, sizeof(int64_t), s);
     return SPX_OK;
   }
   VoxWs w = vox_layout(ws, n_points, batch, max_points);
@@ -268,9 +268,9 @@ extern "C" int spx_voxelize(const float* points, int64_t n_points, int point_str
     g.vs[j] = vsize[j];
     g.grid[j] = grid[j];
   }
-  (void)hipMemsetAsync(w.keys, 0xFF, (size_t)w.slots * 8, s);
-  (void)hipMemsetAsync(w.top, 0x7F, (size_t)w.slots * max_points * 4, s);
-  (void)hipMemsetAsync(w.first, 0xFF, (size_t)(batch + 1) * 4, s);
+  spx_fill_async(w.keys, 0xFF, (size_t)w.slots * 8, s);
+  spx_fill_async(w.top, 0x7F, (size_t)w.slots * max_points * 4, s);
+  spx_fill_async(w.first, 0xFF, (size_t)(batch + 1) * 4, s);
   unsigned nb = (unsigned)w.nblk;
   hipLaunchKernelGGL(k_vox_insert, dim3(nb), dim3(kBlock), 0, s, points, n_points, point_stride, xyz_col, batch_col,
                      batch, g, max_points, w);

@@ -61,7 +61,8 @@ class SparseBasicBlock(spconv.SparseModule):
 def _run_8x_stack(self, batch_dict, with_points_keys):
     voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
     x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(), spatial_shape=self.sparse_shape,
-                                batch_size=batch_dict['batch_size'])
+                                batch_size=batch_dict['batch_size'], n_valid=batch_dict.get('voxel_num_valid', None),
+                                static_caps=batch_dict.get('static_caps', None))
     x = self.conv_input(x)
     x_conv1 = self.conv1(x)
     x_conv2 = self.conv2(x_conv1)
@@ -162,7 +163,9 @@ class VoxelBackBone8x(nn.Module):
         out: encoded_spconv_tensor (+_stride 8), multi_scale_3d_features / _strides."""
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(),
-                                    spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+                                    spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'],
+                                    n_valid=batch_dict.get('voxel_num_valid', None),
+                                    static_caps=batch_dict.get('static_caps', None))
         x = self.conv_input(x)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)

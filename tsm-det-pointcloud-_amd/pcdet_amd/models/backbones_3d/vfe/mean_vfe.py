@@ -38,9 +38,13 @@ class MeanVFE(VFETemplate):
             return batch_dict
         points = batch_dict["points"]
         mode = "train" if self.training else "test"
+        static = batch_dict.get("static_caps", None) is not None      # hipGraph mode: no host sync, rows at capacity
         out = ops.voxelize(points, self.point_cloud_range, self.voxel_size, self.max_points, self.max_voxels[mode],
                            batch_size=int(batch_dict["batch_size"]), batch_col=0, xyz_col=1, feat_col=1,
-                           num_features=self.num_point_features, want_voxels=self.keep_voxels)
+                           num_features=self.num_point_features, want_voxels=self.keep_voxels and not static,
+                           sync=not static)
+        if static:
+            batch_dict["voxel_num_valid"] = out["d_num_voxels"]
         batch_dict["voxel_features"] = out["mean"]
         batch_dict["voxel_coords"] = out["coords"]
         batch_dict["voxel_num_points"] = out["num_points"]

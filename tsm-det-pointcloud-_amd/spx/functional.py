@@ -16,12 +16,13 @@ class _SparseConvFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, feats, weight, bias, pair_f, ld_f, n_dst, pair_b, ld_b, flip_b, scale, shift, relu):
+    def forward(ctx, feats, weight, bias, pair_f, ld_f, n_dst, pair_b, ld_b, flip_b, scale, shift, relu, d_n=None):
         cout, cin = weight.shape[0], weight.shape[-1]
         kvol = weight.numel() // (cout * cin)
         wp = ops.pack_weight(weight, 0)
         sh = shift if shift is not None else bias
-        out = ops.conv_gemm(feats, wp, cout, kvol, pair_f, ld_f, n_dst, flip_k=False, scale=scale, shift=sh, relu=relu)
+        out = ops.conv_gemm(feats, wp, cout, kvol, pair_f, ld_f, n_dst, flip_k=False, scale=scale, shift=sh, relu=relu,
+                            d_n_dst=d_n)
         ctx.save_for_backward(feats, weight)
         ctx.tables = (pair_f, ld_f, n_dst, pair_b, ld_b, flip_b)
         ctx.has_bias = bias is not None
@@ -45,7 +46,7 @@ class _SparseConvFn(torch.autograd.Function):
             dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dout.sum(0)
-        return dfe, dw, db, None, None, None, None, None, None, None, None, None
+        return dfe, dw, db, None, None, None, None, None, None, None, None, None, None
 
 
 def sparse_conv(feats, weight, bias, rb, inverse=False, scale=None, shift=None, relu=False):
@@ -54,25 +55,25 @@ def sparse_conv(feats, weight, bias, rb, inverse=False, scale=None, shift=None, 
     if not inverse:
         if rb.subm:
             return _SparseConvFn.apply(feats, weight, bias, rb.pair, rb.ld, rb.n_out, rb.pair, rb.ld, True, scale,
-                                       shift, relu)
+                                       shift, relu, rb.d_n_out)
         return _SparseConvFn.apply(feats, weight, bias, rb.pair, rb.ld, rb.n_out, rb.pair_bwd, rb.pair_bwd.shape[1],
-                                   False, scale, shift, relu)
+                                   False, scale, shift, relu, rb.d_n_out)
     assert not rb.subm and rb.pair_bwd is not None
     return _SparseConvFn.apply(feats, weight, bias, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in, rb.pair, rb.ld, False,
-                               scale, shift, relu)
+                               scale, shift, relu, rb.d_n_in)
 
 
 class _DenseFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, indices, batch_size, spatial_shape, channels_last):
+    def forward(ctx, feats, indices, batch_size, spatial_shape, channels_last, d_n=None):
         ctx.args = (indices, batch_size, list(spatial_shape), channels_last)
-        return ops.densify(feats, indices, batch_size, spatial_shape, channels_last)
+        return ops.densify(feats, indices, batch_size, spatial_shape, channels_last, d_n=d_n)
 
     @staticmethod
     def backward(ctx, ddense):
         indices, batch_size, spatial_shape, channels_last = ctx.args
-        return ops.densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last), None, None, None, None
+        return ops.densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last), None, None, None, None, None
 
 
-def dense(feats, indices, batch_size, spatial_shape, channels_last=False):
-    return _DenseFn.apply(feats, indices, batch_size, spatial_shape, channels_last)
+def dense(feats, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
+    return _DenseFn.apply(feats, indices, batch_size, spatial_shape, channels_last, d_n)

@@ -80,6 +80,9 @@ class SparseSequential(SparseModule):
                     continue
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
+                if input.n_valid is not None:
+                    raise RuntimeError("static-capacity tensors carry garbage rows beyond n_valid: only sparse modules "
+                                       "and their fused BatchNorm/ReLU epilogue (eval + no_grad) may touch them")
                 if input.indices.shape[0] != 0:
                     input = input.replace_feature(module(input.features))
             else:
@@ -177,7 +180,12 @@ class SparseConvolution(SparseModule):
                 raise ValueError("indice_key %r was built for a different tensor / kernel" % self.indice_key)
             return cached
         if self.subm:
-            rb = ops.subm_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation)
+            rb = ops.subm_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation,
+                                   d_n=x.n_valid)
+        elif x.n_valid is not None:     # static-capacity mode: no host sync, rows at capacity
+            cap = (x.static_caps or {}).get(self.indice_key, None)
+            rb = ops.conv_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
+                                   self.padding, self.dilation, d_n_in=x.n_valid, cap=cap, sync=False)
         else:
             rb = ops.conv_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
                                    self.padding, self.dilation)
@@ -199,12 +207,13 @@ class SparseConvolution(SparseModule):
             out_feats = F_.sparse_conv(feats, self.weight, self.bias, rb, inverse=self.inverse)
         if self.inverse:
             out = SparseConvTensor(out_feats, self._inverse_indices(x, rb), rb.in_shape,
-                                   x.batch_size, x.grid, x.voxel_num, x.indice_dict, x.benchmark)
+                                   x.batch_size, x.grid, x.voxel_num, x.indice_dict, x.benchmark, n_valid=rb.d_n_in,
+                                   static_caps=x.static_caps)
         elif self.subm:
             out = x.replace_feature(out_feats)
         else:
             out = SparseConvTensor(out_feats, rb.out_indices, rb.out_shape, x.batch_size, x.grid, x.voxel_num,
-                                   x.indice_dict, x.benchmark)
+                                   x.indice_dict, x.benchmark, n_valid=rb.d_n_out, static_caps=x.static_caps)
         return out
 
     @staticmethod

@@ -56,15 +56,19 @@ class Rulebook(object):
         self.out_indices, self.out_shape, self.in_shape = out_indices, list(out_shape), list(in_shape)
         self.pair_bwd, self.cnt = pair_bwd, cnt
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
+        # static-capacity (graph) mode: live row counts stay on the device, n_in / n_out above are CAPACITIES
+        self.d_n_in = self.d_n_out = None
 
 
 # ------------------------------------------------------------------------------------------- voxelise
 
 def voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels, batch_size=1, batch_col=-1, xyz_col=0,
-             feat_col=0, num_features=None, want_voxels=True, want_mean=True):
+             feat_col=0, num_features=None, want_voxels=True, want_mean=True, sync=True):
     """GPU hard voxelisation (+ fused MeanVFE).  Returns dict(voxels, coords[M,4], num_points, mean, M).
 
-    One host sync (reads M).  Semantics: include/spx.h §1 / SURVEY.md §8a row a1.
+    sync=True: one host sync (reads M) and exact-size views.  sync=False (static-capacity / graph mode): no sync, every
+    output keeps its capacity rows and the live count is the device tensor `d_num_voxels`.
+    Semantics: include/spx.h §1 / SURVEY.md §8a row a1.
     """
     _need_gpu(points)
     lib = _lib.load()
@@ -86,9 +90,12 @@ def voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels, batc
     check(lib.spx_voxelize(_ptr(points), n, stride, xyz_col, feat_col, c, batch_col, batch_size, f_arr(rng), f_arr(vs),
                            i3(grid), max_points, max_voxels, _ptr(voxels), _ptr(coords), _ptr(num), _ptr(mean),
                            _ptr(d_m), cap, _ptr(ws), wsb, _stream(points)), "spx_voxelize")
+    if not sync:
+        return dict(voxels=voxels, coords=coords, num_points=num, mean=mean, num_voxels=None, d_num_voxels=d_m,
+                    grid_size=grid)
     m = int(d_m.item())
     return dict(voxels=None if voxels is None else voxels[:m], coords=coords[:m], num_points=num[:m],
-                mean=None if mean is None else mean[:m], num_voxels=m, grid_size=grid)
+                mean=None if mean is None else mean[:m], num_voxels=m, d_num_voxels=d_m, grid_size=grid)
 
 
 def mean_vfe(voxels, num_points):
@@ -104,7 +111,8 @@ def mean_vfe(voxels, num_points):
 
 # ------------------------------------------------------------------------------------------- rulebooks
 
-def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False):
+def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None):
+    """d_n: optional device int64[1] live row count (<= indices.shape[0], which is then the capacity)."""
     _need_gpu(indices)
     lib = _lib.load()
     indices = indices.contiguous()
@@ -117,14 +125,19 @@ def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1),
     cnt = torch.zeros((K,), dtype=torch.int32, device=dev) if want_cnt else None
     wsb = lib.spx_subm_rulebook_ws_bytes(n)
     ws = workspace(dev, wsb)
-    check(lib.spx_subm_rulebook(_ptr(indices), n, None, batch_size, i3(spatial_shape), i3(ksize), i3(dilation),
+    check(lib.spx_subm_rulebook(_ptr(indices), n, _ptr(d_n), batch_size, i3(spatial_shape), i3(ksize), i3(dilation),
                                 _ptr(pair), ld, _ptr(cnt), _ptr(ws), wsb, _stream(indices)), "spx_subm_rulebook")
-    return Rulebook(pair, ld, n, n, K, True, indices, spatial_shape, spatial_shape, cnt=cnt, ksize=list(ksize),
-                    stride=[1, 1, 1], padding=[k // 2 for k in ksize], dilation=list(dilation))
+    rb = Rulebook(pair, ld, n, n, K, True, indices, spatial_shape, spatial_shape, cnt=cnt, ksize=list(ksize),
+                  stride=[1, 1, 1], padding=[k // 2 for k in ksize], dilation=list(dilation))
+    rb.d_n_in = rb.d_n_out = d_n
+    return rb
 
 
-def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1), want_cnt=False):
-    """Regular sparse conv rulebook.  One host sync (reads n_out)."""
+def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1), want_cnt=False,
+                  d_n_in=None, cap=None, sync=True):
+    """Regular sparse conv rulebook.  sync=True: one host sync (reads n_out), exact-size out_indices.
+    sync=False (static-capacity / graph mode): no sync; `cap` output rows (default: the no-overflow bound), live counts
+    in rb.d_n_in / rb.d_n_out; rows beyond cap are dropped (overflow <=> rb.d_n_out > cap)."""
     _need_gpu(indices)
     lib = _lib.load()
     indices = indices.contiguous()
@@ -133,7 +146,8 @@ def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, di
     K = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
     dev = indices.device
     out_shape = out_shape_of(spatial_shape, ksize, stride, padding, dilation)
-    cap = int(lib.spx_conv_out_cap(n_in, batch_size, i3(out_shape), i3(ksize), i3(stride)))
+    safe_cap = int(lib.spx_conv_out_cap(n_in, batch_size, i3(out_shape), i3(ksize), i3(stride)))
+    cap = safe_cap if cap is None else max(1, min(int(cap), safe_cap))
     out_idx = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     pair_fwd = torch.empty((K, cap), dtype=torch.int32, device=dev)
     pair_bwd = torch.empty((K, max(n_in, 1)), dtype=torch.int32, device=dev)
@@ -141,12 +155,18 @@ def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, di
     d_n = torch.zeros((1,), dtype=torch.int64, device=dev)
     wsb = lib.spx_conv_rulebook_ws_bytes(n_in, batch_size, i3(out_shape))
     ws = workspace(dev, wsb)
-    check(lib.spx_conv_rulebook(_ptr(indices), n_in, None, batch_size, i3(spatial_shape), i3(out_shape), i3(ksize),
+    check(lib.spx_conv_rulebook(_ptr(indices), n_in, _ptr(d_n_in), batch_size, i3(spatial_shape), i3(out_shape), i3(ksize),
                                 i3(stride), i3(padding), i3(dilation), _ptr(out_idx), _ptr(pair_fwd), _ptr(pair_bwd),
                                 _ptr(cnt), _ptr(d_n), cap, _ptr(ws), wsb, _stream(indices)), "spx_conv_rulebook")
+    if not sync:
+        rb = Rulebook(pair_fwd, cap, n_in, cap, K, False, out_idx, out_shape, spatial_shape, pair_bwd=pair_bwd, cnt=cnt,
+                      ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation))
+        rb.d_n_in, rb.d_n_out = d_n_in, d_n
+        return rb
     n_out = int(d_n.item())
-    return Rulebook(pair_fwd, cap, n_in, n_out, K, False, out_idx[:n_out], out_shape, spatial_shape, pair_bwd=pair_bwd,
-                    cnt=cnt, ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation))
+    rb = Rulebook(pair_fwd, cap, n_in, n_out, K, False, out_idx[:n_out], out_shape, spatial_shape, pair_bwd=pair_bwd,
+                  cnt=cnt, ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation))
+    return rb
 
 
 # ------------------------------------------------------------------------------------------- arithmetic
@@ -163,7 +183,10 @@ def pack_weight(weight, mode):
     return packed
 
 
-def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False):
+def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False,
+              d_n_dst=None):
+    """d_n_dst: optional device int64[1] live destination-row count (n_dst is then the launch capacity; rows beyond the
+    live count are not written)."""
     _need_gpu(src, w_packed, pair)
     lib = _lib.load()
     src = src.contiguous()
@@ -174,7 +197,7 @@ def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=N
     if src.shape[0] == 0:
         return dst.zero_()
     check(lib.spx_conv_gemm(_ptr(src), src.shape[1], _ptr(w_packed), c_dst, kvol, int(bool(flip_k)), _ptr(pair), ld,
-                            n_dst, None, _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(dst), _stream(src)),
+                            n_dst, _ptr(d_n_dst), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(dst), _stream(src)),
           "spx_conv_gemm")
     return dst
 
@@ -200,8 +223,9 @@ def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
 
 # ------------------------------------------------------------------------------------------- densify
 
-def densify(features, indices, batch_size, spatial_shape, channels_last=False):
-    """[N,C] -> logical [B,C,D,H,W].  channels_last=True stores it as [B,H,W,C,D] (see include/spx.h §5)."""
+def densify(features, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
+    """[N,C] -> logical [B,C,D,H,W].  channels_last=True stores it as [B,H,W,C,D] (see include/spx.h §5).
+    d_n: optional device int64[1] live row count."""
     _need_gpu(features, indices)
     lib = _lib.load()
     features = features.contiguous()
@@ -212,7 +236,7 @@ def densify(features, indices, batch_size, spatial_shape, channels_last=False):
         dense = torch.zeros((batch_size, h, w, c, d), dtype=torch.float32, device=dev)
     else:
         dense = torch.zeros((batch_size, c, d, h, w), dtype=torch.float32, device=dev)
-    check(lib.spx_densify(_ptr(features), _ptr(indices), n, None, c, batch_size, i3(spatial_shape),
+    check(lib.spx_densify(_ptr(features), _ptr(indices), n, _ptr(d_n), c, batch_size, i3(spatial_shape),
                           1 if channels_last else 0, _ptr(dense), _stream(features)), "spx_densify")
     return dense.permute(0, 3, 4, 1, 2) if channels_last else dense
 

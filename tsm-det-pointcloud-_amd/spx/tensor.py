@@ -13,7 +13,7 @@ from . import functional as F_
 
 class SparseConvTensor(object):
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None, indice_dict=None,
-                 benchmark=False, **_unused):
+                 benchmark=False, n_valid=None, static_caps=None, **_unused):
         self._features = features
         if indices.dtype != torch.int32:
             indices = indices.int()
@@ -24,6 +24,10 @@ class SparseConvTensor(object):
         self.grid = grid
         self.voxel_num = voxel_num
         self.benchmark = benchmark
+        # static-capacity (hipGraph) mode: rows are a CAPACITY, the live count is the device tensor n_valid (int64[1]);
+        # static_caps maps an indice_key to the output-row capacity of that strided conv
+        self.n_valid = n_valid
+        self.static_caps = static_caps
 
     # spconv 2.x makes .features read-only and offers replace_feature(); spconv 1.x assigned to it.  The
     # reference supports both (spconv_utils.py:28-34), so both work here.
@@ -37,7 +41,7 @@ class SparseConvTensor(object):
 
     def replace_feature(self, feature):
         new = SparseConvTensor(feature, self.indices, self.spatial_shape, self.batch_size, self.grid, self.voxel_num,
-                               self.indice_dict, self.benchmark)
+                               self.indice_dict, self.benchmark, n_valid=self.n_valid, static_caps=self.static_caps)
         return new
 
     def shadow_copy(self):
@@ -61,7 +65,8 @@ class SparseConvTensor(object):
         channels_last_memory=True keeps the logical [B,C,D,H,W] shape but stores it as [B,H,W,C,D], so the
         reference's `.view(N, C*D, H, W)` (height_compression.py:22-23) yields a channels_last BEV map.
         """
-        out = F_.dense(self._features, self.indices, self.batch_size, self.spatial_shape, channels_last_memory)
+        out = F_.dense(self._features, self.indices, self.batch_size, self.spatial_shape, channels_last_memory,
+                       self.n_valid)
         if not channels_first:
             return out.permute(0, 2, 3, 4, 1).contiguous()
         return out
