@@ -228,6 +228,23 @@ int spx_anchor_loss(const float *cls_preds, const float *box_preds, const float 
                     float beta, float alpha, float *losses, float *dcls, float *dbox, float *ddir, void *ws,
                     size_t ws_bytes, spx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * 9. BatchNorm1d (+ReLU) over sparse feature rows, training mode
+ *    replaces: nn.BatchNorm1d(C, eps=1e-3, momentum=0.01) + nn.ReLU applied to SparseConvTensor.features by
+ *      SparseSequential, reference pcdet/models/backbones_3d/spconv_backbone.py:81,24-33 (three torch launches forward,
+ *      three backward per layer).  C must divide 1024 and be a multiple of 4.
+ *    fwd: batch mean / biased variance over the n rows -> save_mean, save_invstd; running_mean/var (nullable) updated
+ *         with `momentum` (unbiased variance), y = relu?((x-mean)*invstd*gamma + beta)
+ *    bwd: dx, dgamma, dbeta from dy (ReLU mask taken from y when relu != 0)
+ * ---------------------------------------------------------------------------------------------- */
+size_t spx_bn_relu_ws_bytes(int c);
+int spx_bn_relu_fwd(const float *x, int64_t n, const int64_t *d_n, int c, const float *gamma, const float *beta,
+                    float *running_mean, float *running_var, float momentum, float eps, int relu, float *y,
+                    float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, spx_stream_t stream);
+int spx_bn_relu_bwd(const float *x, const float *y, const float *dy, int64_t n, int c, const float *gamma,
+                    const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma, float *dbeta,
+                    void *ws, size_t ws_bytes, spx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -394,3 +394,41 @@ def test_nms_utils_api(orc):
     assert torch.equal(sel.cpu(), ref)
     iou3d = iou3d_nms_utils.boxes_iou3d_gpu(boxes[:20].to(_dev()), boxes[:20].to(_dev()))
     assert float((iou3d.diagonal() - 1).abs().max()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ BatchNorm1d + ReLU (row a10)
+
+@pytest.mark.parametrize("n,c,relu", [(5000, 16, True), (83083, 32, True), (40001, 64, False), (777, 128, True), (2, 64, True)])
+def test_fused_bn_relu_train_matches_torch(n, c, relu):
+    """csrc/bn_relu.hip against nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU in training mode: output, running
+    statistics, and all three gradients."""
+    import spx
+    from spx import functional as F_
+    dev = _dev()
+    k = 1.0 if n > 16 else 50.0   # two rows: 1/std of a 2-sample variance amplifies single ulps
+    g = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=g) * torch.linspace(0.5, 3.0, c) + torch.linspace(-2, 2, c)).to(dev)
+    dy = torch.randn(n, c, generator=g).to(dev)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev).train()
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        ref.bias.copy_(torch.randn(c, generator=g) * 0.2)
+    import copy
+    mine = copy.deepcopy(ref)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(dy)
+    xm = x.clone().requires_grad_(True)
+    ym = F_.bn_relu_train(xm, mine, relu)
+    ym.backward(dy)
+    _close(ym.detach().cpu().numpy(), yr.detach().cpu().numpy(), tol=2e-5 * k)
+    _close(mine.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), tol=1e-6)
+    _close(mine.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), tol=1e-6)
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    _close(xm.grad.cpu().numpy(), xr.grad.cpu().numpy(), tol=5e-5 * k)
+    _close(mine.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), tol=5e-5 * k)
+    _close(mine.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), tol=5e-5 * k)
+    # bitwise reproducible
+    xm2 = x.clone().requires_grad_(True)
+    assert torch.equal(F_.bn_relu_train(xm2, copy.deepcopy(ref), relu), ym)

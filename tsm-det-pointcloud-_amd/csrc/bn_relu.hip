@@ -1,0 +1,218 @@
+// bn_relu.hip — BatchNorm1d (+ReLU) over the rows of a sparse feature matrix, training mode.
+//
+// Restates nn.BatchNorm1d(C, eps, momentum) followed by nn.ReLU on SparseConvTensor.features [N, C], as the reference
+// builds them at pcdet/models/backbones_3d/spconv_backbone.py:81,26-27: batch statistics over ALL active rows of the
+// batch, biased variance for normalisation, unbiased for the running estimate.
+// The stock kernels cost three launches forward and three backward per layer and stream [N,C] at ~0.4 TB/s; here
+//   forward : k_bn_stats (one coalesced float4 pass, per-block partial sums) -> k_bn_finalize (fp64 combine, running
+//             statistics update) -> k_bn_apply (normalise + affine + ReLU, one read one write)
+//   backward: k_bn_bwd_reduce (sum dz, sum dz*xhat with the ReLU mask applied on the fly) -> k_bn_bwd_finalize ->
+//             k_bn_bwd_apply (dx)
+// Partials are combined in a fixed order (no float atomics): bitwise reproducible.
+#include "spx_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMaxBlocks = 1024;
+
+// grid-stride over float4 elements of x[N][C]; because 256*4 % C == 0 is NOT assumed, each thread recomputes its channel
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ x, const float* __restrict__ y,
+                                                   const float* __restrict__ dy, const float* __restrict__ mean,
+                                                   const float* __restrict__ invstd, int64_t n, const int64_t* d_n, int C,
+                                                   int relu, float* __restrict__ partial /*[grid][2][C]*/) {
+  __shared__ float sm[256][8];   // per-thread partials (4 channels x {a, b})
+  const int64_t nlive = spx_live_n(d_n, n);
+  const int64_t total4 = nlive * C / 4;
+  // every thread keeps the same 4 channels for its whole walk when the stride (grid*256*4) is a multiple of C;
+  // the launcher guarantees that (C divides 1024)
+  const int64_t start = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int c0 = (int)((start * 4) % C);
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f}, is = f32x4{1.f, 1.f, 1.f, 1.f};
+  if (BWD) {
+    mu = *reinterpret_cast<const f32x4*>(mean + c0);
+    is = *reinterpret_cast<const f32x4*>(invstd + c0);
+  }
+  for (int64_t i = start; i < total4; i += stride) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    if (!BWD) {
+      a += v;
+      b += v * v;
+    } else {
+      f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+      if (relu) {
+        f32x4 o = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+      }
+      a += g;
+      b += g * ((v - mu) * is);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sm[threadIdx.x][e] = a[e];
+    sm[threadIdx.x][4 + e] = b[e];
+  }
+  __syncthreads();
+  // threads t, t + C/4, t + 2C/4, ... hold the same 4 channels: one thread per channel adds them in a fixed order
+  const int G = C / 4;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / 4, e = c % 4;
+    float sa = 0.f, sb = 0.f;
+    for (int t = g; t < 256; t += G) {
+      sa += sm[t][e];
+      sb += sm[t][4 + e];
+    }
+    partial[(size_t)blockIdx.x * 2 * C + c] = sa;
+    partial[(size_t)blockIdx.x * 2 * C + C + c] = sb;
+  }
+}
+
+// one wave per channel: lane l adds partials l, l+64, ... in fp64, then a fixed-order shuffle tree
+__device__ __forceinline__ void wave_sum2(double& s, double& q) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    s += __shfl_down(s, d, 64);
+    q += __shfl_down(q, d, 64);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ partial, int nblk, int C, int64_t n,
+                                                    const int64_t* d_n, float eps, float momentum, float* __restrict__ mean,
+                                                    float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) {
+    s += (double)partial[(size_t)b * 2 * C + c];
+    q += (double)partial[(size_t)b * 2 * C + C + c];
+  }
+  wave_sum2(s, q);
+  if (threadIdx.x != 0) return;
+  const double N = (double)spx_live_n(d_n, n);
+  double m = N > 0 ? s / N : 0.0;
+  double var = N > 0 ? q / N - m * m : 0.0;
+  if (var < 0) var = 0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unbiased = N > 1 ? var * N / (N - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean,
+                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int64_t n, const int64_t* d_n, int C,
+                                                  int relu, float* __restrict__ y) {
+  const int64_t total4 = spx_live_n(d_n, n) * C / 4;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const int c0 = (int)((i * 4) % C);
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
+    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    f32x4 o = (v - mu) * is * ga + be;
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(y)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, int C,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) {
+    s += (double)partial[(size_t)b * 2 * C + c];
+    q += (double)partial[(size_t)b * 2 * C + C + c];
+  }
+  wave_sum2(s, q);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ dy, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                      int64_t n, int C, int relu, float* __restrict__ dx) {
+  const int64_t total4 = n * C / 4;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const float invN = 1.0f / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const int c0 = (int)((i * 4) % C);
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    if (relu) {
+      f32x4 o = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+    }
+    f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
+    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+    f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c0), db = *reinterpret_cast<const f32x4*>(dbeta + c0);
+    f32x4 xh = (v - mu) * is;
+    reinterpret_cast<f32x4*>(dx)[i] = ga * is * (g - db * invN - xh * dg * invN);
+  }
+}
+
+static inline int bn_blocks(int64_t n, int C) {
+  int64_t total4 = n * C / 4;
+  int64_t nb = (total4 + 256 * 8 - 1) / (256 * 8);
+  if (nb > kMaxBlocks) nb = kMaxBlocks;
+  if (nb < 1) nb = 1;
+  // stride = nb*256 float4 = nb*1024 floats must be a multiple of C so that a thread keeps its channels: C | 1024
+  return (int)nb;
+}
+
+}  // namespace
+
+extern "C" size_t spx_bn_relu_ws_bytes(int c) { return spx_align((size_t)kMaxBlocks * 2 * c * 4); }
+
+extern "C" int spx_bn_relu_fwd(const float* x, int64_t n, const int64_t* d_n, int c, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, int relu, float* y,
+                               float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, spx_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || n < 0 || c <= 0) return SPX_ERR_INVALID_ARG;
+  if (c % 4 != 0 || 1024 % c != 0) return SPX_ERR_UNSUPPORTED;   // 4,8,16,...,1024
+  if (!ws || ws_bytes < spx_bn_relu_ws_bytes(c)) return SPX_ERR_WORKSPACE;
+  hipStream_t s = spx_s(stream);
+  float* partial = reinterpret_cast<float*>(ws);
+  int nb = bn_blocks(n, c);
+  hipLaunchKernelGGL((k_bn_reduce<false>), dim3(nb), dim3(256), 0, s, x, nullptr, nullptr, nullptr,
+                     nullptr, n, d_n, c, relu, partial);
+  hipLaunchKernelGGL(k_bn_finalize, dim3(c), dim3(64), 0, s, partial, nb, c, n, d_n, eps, momentum, save_mean,
+                     save_invstd, running_mean, running_var);
+  if (n > 0)
+    hipLaunchKernelGGL(k_bn_apply, dim3(nb), dim3(256), 0, s, x, save_mean, save_invstd, gamma, beta, n, d_n, c, relu, y);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}
+
+extern "C" int spx_bn_relu_bwd(const float* x, const float* y, const float* dy, int64_t n, int c, const float* gamma,
+                               const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
+                               float* dbeta, void* ws, size_t ws_bytes, spx_stream_t stream) {
+  if (!x || !y || !dy || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || n <= 0 || c <= 0)
+    return SPX_ERR_INVALID_ARG;
+  if (c % 4 != 0 || 1024 % c != 0) return SPX_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < spx_bn_relu_ws_bytes(c)) return SPX_ERR_WORKSPACE;
+  hipStream_t s = spx_s(stream);
+  float* partial = reinterpret_cast<float*>(ws);
+  int nb = bn_blocks(n, c);
+  hipLaunchKernelGGL((k_bn_reduce<true>), dim3(nb), dim3(256), 0, s, x, y, dy, save_mean, save_invstd,
+                     n, nullptr, c, relu, partial);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(c), dim3(64), 0, s, partial, nb, c, dgamma, dbeta);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(nb), dim3(256), 0, s, x, y, dy, save_mean, save_invstd, gamma, dgamma, dbeta, n,
+                     c, relu, dx);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}

@@ -47,6 +47,10 @@ SIGNATURES = {
     "spx_nms_ws_bytes": (_sz, [_i64]),
     "spx_nms_bev": (_int, [_vp, _i64, ctypes.c_float, _int, _vp, _vp, _vp, _sz, _vp]),
     "spx_assign_targets_ws_bytes": (_sz, [_int, _int, _int]),
+    "spx_bn_relu_ws_bytes": (_sz, [_int]),
+    "spx_bn_relu_fwd": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _int, _vp, _vp,
+                               _vp, _vp, _sz, _vp]),
+    "spx_bn_relu_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spx_anchor_loss_ws_bytes": (_sz, [_int, _i64]),
     "spx_anchor_loss": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _int, _int, ctypes.c_float, ctypes.c_float,
                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _sz,

@@ -77,3 +77,29 @@ class _DenseFn(torch.autograd.Function):
 
 def dense(feats, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
     return _DenseFn.apply(feats, indices, batch_size, spatial_shape, channels_last, d_n)
+
+
+class _BNReLUFn(torch.autograd.Function):
+    """Training-mode BatchNorm1d (+ReLU) on sparse feature rows: libspx kernels forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        y, mean, invstd = ops.bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu)
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.relu = relu
+        ctx.mark_non_differentiable(running_mean, running_var) if running_mean is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.bn_relu_bwd(x, y, dy, gamma, mean, invstd, ctx.relu)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_relu_train(x, bn, relu):
+    """x [N, C] through `bn` (nn.BatchNorm1d in training mode, affine, tracking running stats) and optionally ReLU."""
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BNReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, relu)

@@ -79,6 +79,13 @@ class SparseSequential(SparseModule):
                     i += consumed
                     continue
                 input = module(input)
+                tail = _train_bn_tail(mods, i, input) if isinstance(input, SparseConvTensor) else None
+                if tail is not None:
+                    # training: BatchNorm1d (batch statistics) + ReLU as one libspx kernel pair instead of 3 + 3 launches
+                    bn, relu, consumed = tail
+                    input = input.replace_feature(F_.bn_relu_train(input.features, bn, relu))
+                    i += consumed
+                    continue
             elif isinstance(input, SparseConvTensor):
                 if input.n_valid is not None:
                     raise RuntimeError("static-capacity tensors carry garbage rows beyond n_valid: only sparse modules "
@@ -89,6 +96,20 @@ class SparseSequential(SparseModule):
                 input = module(input)
             i += 1
         return input
+
+
+def _train_bn_tail(mods, i, x):
+    """(bn, relu, modules consumed) when mods[i+1:] starts with a training-mode affine BatchNorm1d[, ReLU] that libspx's
+    fused kernels cover; else None (the torch modules then run as usual)."""
+    if i + 1 >= len(mods) or x.n_valid is not None:
+        return None
+    bn = mods[i + 1]
+    f = x.features
+    if not (isinstance(bn, nn.BatchNorm1d) and bn.training and bn.affine and bn.track_running_stats and f.is_cuda
+            and f.dtype == torch.float32 and f.shape[0] > 1 and ops.bn_relu_supported(f.shape[1])):
+        return None
+    relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+    return bn, relu, (3 if relu else 2)
 
 
 def _fusable_tail(conv, mods, i):

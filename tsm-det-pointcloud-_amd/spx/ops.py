@@ -335,3 +335,44 @@ def anchor_loss(cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, d
                               float(dir_weight), float(beta), float(alpha), _ptr(losses), _ptr(dcls), _ptr(dbox),
                               _ptr(ddir), _ptr(ws), wsb, _stream(cls_preds)), "spx_anchor_loss")
     return losses, dcls, dbox, ddir
+
+
+# ------------------------------------------------------------------------------------------- BatchNorm1d (+ReLU), training
+
+def bn_relu_supported(c):
+    return c % 4 == 0 and 1024 % c == 0
+
+
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    """Training-mode BatchNorm1d over the rows of x [N, C] (+ReLU).  Updates running_mean / running_var in place.
+    Returns y, save_mean, save_invstd."""
+    _need_gpu(x, gamma, beta)
+    lib = _lib.load()
+    x = x.contiguous()
+    n, c = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
+    wsb = lib.spx_bn_relu_ws_bytes(c)
+    ws = workspace(x.device, wsb)
+    check(lib.spx_bn_relu_fwd(_ptr(x), n, None, c, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                              float(momentum), float(eps), int(bool(relu)), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(ws),
+                              wsb, _stream(x)), "spx_bn_relu_fwd")
+    return y, mean, invstd
+
+
+def bn_relu_bwd(x, y, dy, gamma, mean, invstd, relu):
+    _need_gpu(x, y, dy)
+    lib = _lib.load()
+    dy = dy.contiguous()
+    n, c = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty((c,), dtype=torch.float32, device=x.device)
+    dbeta = torch.empty((c,), dtype=torch.float32, device=x.device)
+    if n == 0:
+        return dx, dgamma.zero_(), dbeta.zero_()
+    wsb = lib.spx_bn_relu_ws_bytes(c)
+    ws = workspace(x.device, wsb)
+    check(lib.spx_bn_relu_bwd(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(mean), _ptr(invstd), int(bool(relu)),
+                              _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream(x)), "spx_bn_relu_bwd")
+    return dx, dgamma, dbeta
