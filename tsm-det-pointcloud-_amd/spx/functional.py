@@ -8,6 +8,28 @@ import torch
 from . import ops
 
 
+def _packed(weight, mode):
+    """MFMA-ordered copy of `weight`, cached on the parameter until it is modified in place (optimizer step, load).
+    While a hipGraph is being captured the pack kernel is always recorded, so a replay never reads a stale copy."""
+    if weight.is_cuda and torch.cuda.is_current_stream_capturing():
+        return ops.pack_weight(weight, mode)
+    cache = getattr(weight, "_spx_packed", None)
+    if cache is None:
+        cache = {}
+        try:
+            weight._spx_packed = cache
+        except AttributeError:
+            return ops.pack_weight(weight, mode)
+    key = (mode, weight.data_ptr())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == weight._version:
+        return hit[1]
+    wp = ops.pack_weight(weight, mode)
+    cache.clear()
+    cache[key] = (weight._version, wp)
+    return wp
+
+
 class _SparseConvFn(torch.autograd.Function):
     """out = gather(src, pair_f) (*) W   — one sparse conv application.
 
@@ -19,7 +41,7 @@ class _SparseConvFn(torch.autograd.Function):
     def forward(ctx, feats, weight, bias, pair_f, ld_f, n_dst, pair_b, ld_b, flip_b, scale, shift, relu, d_n=None):
         cout, cin = weight.shape[0], weight.shape[-1]
         kvol = weight.numel() // (cout * cin)
-        wp = ops.pack_weight(weight, 0)
+        wp = _packed(weight, 0)
         sh = shift if shift is not None else bias
         out = ops.conv_gemm(feats, wp, cout, kvol, pair_f, ld_f, n_dst, flip_k=False, scale=scale, shift=sh, relu=relu,
                             d_n_dst=d_n)
