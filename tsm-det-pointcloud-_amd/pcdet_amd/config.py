@@ -93,7 +93,8 @@ def cfg_from_list(cfg_list, config):
                 ck, cv = item.split(":")
                 cur[ck] = type(cur[ck])(cv)
         elif type(value) != type(cur) and isinstance(cur, list):
-            parts = value.split(",")
+            # "a,b" stays a string after literal_eval, "3,3" becomes a tuple: accept both
+            parts = value.split(",") if isinstance(value, str) else list(value)
             d[sub] = [type(cur[0])(x) for x in parts]
         else:
             assert type(value) == type(cur), "type {} does not match original type {}".format(type(value), type(cur))
