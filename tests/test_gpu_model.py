@@ -374,3 +374,59 @@ def test_graphed_static_capacity_forward_matches_dynamic():
     tiny(pts)
     bad = tiny.overflowed()
     assert "spconv2" in bad and bad["spconv2"][0] > bad["spconv2"][1]
+
+
+def test_bev_block_rewrites_match_plain_sequential():
+    """BaseBEVBackbone._run_block (pad folded into the conv, fused BN2d+ReLU through libspx on the channels_last row
+    view) against nn.Sequential.forward of the very same modules: outputs, input gradient, parameter gradients and
+    running statistics.  Tolerance 2e-5 relative (fp32; BN batch statistics are summed in a different order)."""
+    import torch.nn as nn
+    from pcdet_amd.models.backbones_2d import base_bev_backbone as bb
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    C = 128
+    seq = nn.Sequential(nn.ZeroPad2d(1), nn.Conv2d(64, C, 3, stride=1, padding=0, bias=False),
+                        nn.BatchNorm2d(C, eps=1e-3, momentum=0.01), nn.ReLU(),
+                        nn.Conv2d(C, C, 3, padding=1, bias=False), nn.BatchNorm2d(C, eps=1e-3, momentum=0.01),
+                        nn.ReLU()).to(dev).to(memory_format=torch.channels_last).train()
+    ref = copy.deepcopy(seq)
+    x = torch.randn(2, 64, 96, 88, device=dev).to(memory_format=torch.channels_last)
+    g = torch.randn(2, C, 96, 88, device=dev).to(memory_format=torch.channels_last)
+    old = bb._FUSED_BN_MIN_ELEMS
+    bb._FUSED_BN_MIN_ELEMS = 0                      # force the fused path at this small size
+    try:
+        xa = x.clone().requires_grad_(True)
+        ya = bb._run_block(seq, xa)
+        ya.backward(g)
+    finally:
+        bb._FUSED_BN_MIN_ELEMS = old
+    xb = x.clone().requires_grad_(True)
+    yb = ref(xb)
+    yb.backward(g)
+    assert ya.shape == yb.shape and ya.is_contiguous(memory_format=torch.channels_last)
+    assert _rel(ya, yb) < 2e-5 and _rel(xa.grad, xb.grad) < 2e-5
+    for (n, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+        assert _rel(p.grad, q.grad) < 5e-5, n
+    for (n, p), (_, q) in zip(seq.named_buffers(), ref.named_buffers()):
+        assert _rel(p.float(), q.float()) < 1e-5, n
+
+
+def test_fused_head_convs_match_separate_convs():
+    """AnchorHeadSingle._heads (one conv over the concatenated filters; a GEMM under no_grad) against the three
+    separate 1x1 convs of the reference formulation, values and gradients."""
+    _, ds, model = _build(0)
+    head = model.dense_head.cuda()
+    torch.manual_seed(5)
+    x = torch.randn(2, 512, 40, 32, device="cuda").to(memory_format=torch.channels_last).requires_grad_(True)
+    outs = head._heads(x)
+    refs = [c(x).permute(0, 2, 3, 1).contiguous() for c in (head.conv_cls, head.conv_box, head.conv_dir_cls)]
+    for a, b in zip(outs, refs):
+        assert a.shape == b.shape and a.is_contiguous() and _rel(a, b) < 1e-5
+    gs = [torch.randn_like(r) for r in refs]
+    ga = torch.autograd.grad(outs, [x, head.conv_box.weight, head.conv_cls.bias], gs)
+    gb = torch.autograd.grad(refs, [x, head.conv_box.weight, head.conv_cls.bias], gs)
+    for a, b in zip(ga, gb):
+        assert _rel(a, b) < 2e-5
+    with torch.no_grad():
+        for a, b in zip(head._heads(x), refs):
+            assert _rel(a, b) < 1e-5

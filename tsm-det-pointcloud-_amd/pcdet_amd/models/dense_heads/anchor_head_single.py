@@ -3,6 +3,7 @@ direction) + anchor decode.  Reads `encoded_bev_features` (list, the fork's key)
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .anchor_head_template import AnchorHeadTemplate
 
@@ -28,6 +29,21 @@ class AnchorHeadSingle(AnchorHeadTemplate):
         nn.init.constant_(self.conv_cls.bias, -np.log((1 - pi) / pi))
         nn.init.normal_(self.conv_box.weight, mean=0, std=0.001)
 
+    def _heads(self, x):
+        """The three 1x1 convs of reference anchor_head_single.py:54-68 as ONE conv over the concatenated filters: the
+        512-channel map is read once (and its gradient produced by one dgrad instead of three plus two adds).  Every
+        output channel is the same dot product as in the separate convs; parameters stay `conv_cls/conv_box/
+        conv_dir_cls` (state_dict compatible)."""
+        convs = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
+        w = torch.cat([c.weight for c in convs], 0)
+        b = torch.cat([c.bias for c in convs], 0)
+        if not torch.is_grad_enabled() and x.is_contiguous(memory_format=torch.channels_last):
+            y = F.linear(x.permute(0, 2, 3, 1), w.flatten(1), b)          # inference: a plain GEMM over pixels
+        else:
+            y = F.conv2d(x, w, b).permute(0, 2, 3, 1)
+        outs = [t.contiguous() for t in torch.split(y, [c.out_channels for c in convs], dim=3)]
+        return outs[0], outs[1], (outs[2] if len(outs) > 2 else None)
+
     def forward(self, data_dict):
         if data_dict.get('encoded_bev_features', None) is not None:
             feats = data_dict['encoded_bev_features']
@@ -35,15 +51,11 @@ class AnchorHeadSingle(AnchorHeadTemplate):
         else:
             x = data_dict['spatial_features_2d']
         x = x.float()
-        cls_preds = self.conv_cls(x).permute(0, 2, 3, 1).contiguous()   # [N, H, W, C]
-        box_preds = self.conv_box(x).permute(0, 2, 3, 1).contiguous()
+        cls_preds, box_preds, dir_cls_preds = self._heads(x)             # each [N, H, W, C]
         self.forward_ret_dict['cls_preds'] = cls_preds
         self.forward_ret_dict['box_preds'] = box_preds
-        if self.conv_dir_cls is not None:
-            dir_cls_preds = self.conv_dir_cls(x).permute(0, 2, 3, 1).contiguous()
+        if dir_cls_preds is not None:
             self.forward_ret_dict['dir_cls_preds'] = dir_cls_preds
-        else:
-            dir_cls_preds = None
         if self.training:
             self.forward_ret_dict.update(self.assign_targets(gt_boxes=data_dict['gt_boxes']))
         if not self.training or self.predict_boxes_when_training:
