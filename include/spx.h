@@ -145,6 +145,7 @@ int spx_conv_rulebook(const int32_t *idx, int64_t n_in, const int64_t *d_n_in, i
  *      -> both are spx_conv_gemm: "rows of `src` gathered through `pair`, contracted with packed weights".
  *    Optional fused epilogue:  y = acc*scale[c] + shift[c] (both nullable), then ReLU if relu != 0.
  *    wgrad   : dw[co][k][ci] = sum_o dout[o,co] * in[pair[k*ld+o], ci]                (reference layout, fp32)
+ *              (fixed summation order: bitwise reproducible from run to run)
  * ---------------------------------------------------------------------------------------------- */
 int spx_pack_weight(const float *w, int cout, int kvol, int cin, int mode, float *packed, spx_stream_t stream);
 

@@ -208,8 +208,11 @@ def test_conv_fwd_dgrad_wgrad_vs_oracle(cin, cout, orc):
         else:
             din = ops.conv_gemm(dout.to(dev), wt, cin, 27, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in)
         _close(din.cpu().numpy(), orc.conv_dgrad(dout.numpy(), w.numpy(), pair_np, rb.n_in))
+        ref_dw = orc.conv_wgrad(feat.numpy(), dout.numpy(), pair_np, tuple(w.shape))
         dw = ops.conv_wgrad(feat.to(dev), dout.to(dev), rb.pair, rb.ld, rb.n_out, tuple(w.shape))
-        _close(dw.cpu().numpy(), orc.conv_wgrad(feat.numpy(), dout.numpy(), pair_np, tuple(w.shape)), tol=1e-4)
+        _close(dw.cpu().numpy(), ref_dw, tol=1e-4)
+        # fixed summation order: a second launch is bitwise identical
+        assert torch.equal(dw, ops.conv_wgrad(feat.to(dev), dout.to(dev), rb.pair, rb.ld, rb.n_out, tuple(w.shape)))
 
 
 def test_conv_full_size_linearity_and_oracle(orc):
@@ -233,6 +236,14 @@ def test_conv_full_size_linearity_and_oracle(orc):
     _close(fx.cpu().numpy(), ref)
     # determinism: bitwise identical on a second launch
     assert torch.equal(fx, ops.conv_gemm(x, wp, 64, 27, rb.pair, rb.ld, rb.n_out))
+    # weight gradient at full size: oracle comparison, bilinearity in dout, fixed summation order
+    dout = torch.randn(rb.n_out, 64, generator=g).to(dev)
+    dw = ops.conv_wgrad(x, dout, rb.pair, rb.ld, rb.n_out, tuple(w.shape))
+    ref_dw = orc.conv_wgrad(x.cpu().numpy(), dout.cpu().numpy(), rb.pair[:, :rb.n_out].cpu().numpy(), tuple(w.shape))
+    _close(dw.cpu().numpy(), ref_dw, tol=1e-4)
+    dw2 = ops.conv_wgrad(x, 2.0 * dout, rb.pair, rb.ld, rb.n_out, tuple(w.shape))
+    assert torch.equal(dw2, 2.0 * dw)                                                   # scaling by 2 is exact in fp32
+    assert torch.equal(dw, ops.conv_wgrad(x, dout, rb.pair, rb.ld, rb.n_out, tuple(w.shape)))
 
 
 # ------------------------------------------------------------------------------------------ densify

@@ -122,7 +122,7 @@ def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1),
     dev = indices.device
     ld = max(n, 1)
     pair = torch.empty((K, ld), dtype=torch.int32, device=dev)
-    cnt = torch.zeros((K,), dtype=torch.int32, device=dev) if want_cnt else None
+    cnt = torch.empty((K,), dtype=torch.int32, device=dev) if want_cnt else None   # zeroed by the library
     wsb = lib.spx_subm_rulebook_ws_bytes(n)
     ws = workspace(dev, wsb)
     check(lib.spx_subm_rulebook(_ptr(indices), n, _ptr(d_n), batch_size, i3(spatial_shape), i3(ksize), i3(dilation),
@@ -151,7 +151,7 @@ def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, di
     out_idx = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     pair_fwd = torch.empty((K, cap), dtype=torch.int32, device=dev)
     pair_bwd = torch.empty((K, max(n_in, 1)), dtype=torch.int32, device=dev)
-    cnt = torch.zeros((K,), dtype=torch.int32, device=dev) if want_cnt else None
+    cnt = torch.empty((K,), dtype=torch.int32, device=dev) if want_cnt else None   # zeroed by the library
     d_n = torch.zeros((1,), dtype=torch.int64, device=dev)
     wsb = lib.spx_conv_rulebook_ws_bytes(n_in, batch_size, i3(out_shape))
     ws = workspace(dev, wsb)
