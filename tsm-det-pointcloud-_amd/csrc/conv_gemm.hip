@@ -8,13 +8,13 @@
 //   1. reads its rows' source indices pair[k][rows] (coalesced 64 B),
 //   2. skips the offset entirely when no row of the wave has a neighbour there (wave-uniform ballot),
 //      and skips 16-row M-tiles that have none,
-//   3. gathers the source rows straight into the MFMA A-operand registers: lane (r, q) of a 16-row
-//      tile loads the q-th quarter of row r as 16-byte pieces, so the 4 lanes of a row read 64
-//      contiguous bytes per instruction,
+//   3. gathers the source rows straight into the MFMA A-operand registers: the four lanes (r, q=0..3) of row r
+//      load the four 16-byte pieces of ONE 64-byte sector of that row per instruction (16 sectors per wave
+//      instruction; an earlier mapping that gave each lane its own quarter of the row touched 64),
 //   4. issues v_mfma_f32_16x16x4_f32 (exact fp32, the reference's precision: spconv fp32, no TF32).
-// The GEMM K axis is PERMUTED so that each lane's operand values are contiguous in memory:
-// k-step j of lane quarter q is source channel q*(c_src/4)+j.  The weights are pre-packed by
-// spx_pack_weight in exactly that order, lane-linear, so a B fragment is one coalesced 1 KiB read.
+// The GEMM K axis is PERMUTED so that each lane's operand values are contiguous in memory: k-step j = 4jg + e of lane
+// quarter q is source channel 16jg + 4q + e.  The weights are pre-packed by spx_pack_weight in exactly that order,
+// lane-linear, so a B fragment is one coalesced 1 KiB read.
 //
 // Serves reference call sites pcdet/models/backbones_3d/spconv_backbone.py:86,93,98-100,105-107,
 // 112-114,121 (forward) and their autograd (dgrad) — spconv itself is not vendored.
@@ -23,6 +23,12 @@
 #include <type_traits>
 
 #include "spx_common.h"
+
+#ifdef SPX_CV_DIAG
+// diagnostic build only (never shipped): per-wave cycle stamps, see tools/conv_diag.py
+__device__ unsigned long long* g_cv_diag = nullptr;
+extern "C" int spx_diag_set_conv(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cv_diag), &p, sizeof(p)); }
+#endif
 
 namespace {
 
@@ -37,7 +43,7 @@ __device__ __forceinline__ float w_elem(const float* w, int cout, int K, int cin
   return mode == 0 ? w[((size_t)cd * K + k) * cin + cs] : w[((size_t)cs * K + k) * cin + cd];
 }
 
-// MFMA order: [k][nt][jg][lane][e]; lane = 16q + c ; k-step j = 4jg + e ; cs = q*(CS/4) + j ; cd = 16nt + c
+// MFMA order: [k][nt][jg][lane][e]; lane = 16q + c ; k-step j = 4jg + e ; cs = 16jg + 4q + e ; cd = 16nt + c
 __global__ void k_pack_mfma(const float* __restrict__ w, int cout, int K, int cin, int mode, int CS, int CD,
                             float* __restrict__ out) {
   int total = K * CS * CD;
@@ -51,7 +57,7 @@ __global__ void k_pack_mfma(const float* __restrict__ w, int cout, int K, int ci
   int nt = rest % NT;
   int k = rest / NT;
   int q = lane >> 4, c = lane & 15;
-  int cs = q * (CS / 4) + 4 * jg + e, cd = 16 * nt + c;
+  int cs = 16 * jg + 4 * q + e, cd = 16 * nt + c;
   out[t] = w_elem(w, cout, K, cin, mode, k, cs, cd);
 }
 
@@ -79,6 +85,10 @@ __global__ __launch_bounds__(64 * WPB) void k_conv_mfma(const float* __restrict_
   const int64_t nlive = spx_live_n(d_n, n);
   const int64_t row_base = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * (16 * MT);
   if (row_base >= nlive) return;
+#ifdef SPX_CV_DIAG
+  const unsigned long long d_t0 = __builtin_amdgcn_s_memtime(), d_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long d_units = 0;
+#endif
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -104,6 +114,9 @@ __global__ __launch_bounds__(64 * WPB) void k_conv_mfma(const float* __restrict_
       any |= mv[m];
     }
     if (!any) continue;  // wave-uniform
+#ifdef SPX_CV_DIAG
+    d_units += 1;
+#endif
 #pragma unroll
     for (int jg = 0; jg < JG; ++jg) {
       f32x4 b[NT];
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(64 * WPB) void k_conv_mfma(const float* __restrict_
         if (!mv[m]) continue;  // wave-uniform
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
         if (id[m] >= 0)
-          a = *reinterpret_cast<const f32x4*>(src + (size_t)id[m] * CS + q * (CS / 4) + 4 * jg);
+          a = *reinterpret_cast<const f32x4*>(src + (size_t)id[m] * CS + 16 * jg + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -124,6 +137,15 @@ __global__ __launch_bounds__(64 * WPB) void k_conv_mfma(const float* __restrict_
     }
   }
 
+#ifdef SPX_CV_DIAG
+  if (g_cv_diag && lane == 0) {
+    unsigned long long* o = g_cv_diag + ((size_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * 4;
+    o[0] = __builtin_amdgcn_s_memtime() - d_t0;        // wave lifetime before the epilogue, core cycles
+    o[1] = d_units;                                    // (tile, offset) units executed
+    o[2] = d_r0;                                       // start, 100 MHz ticks (global clock)
+    o[3] = __builtin_amdgcn_s_memrealtime();           // end
+  }
+#endif
   // epilogue: C layout col = lane&15, row = 4*(lane>>4) + e ; optional y = acc*scale + shift, ReLU
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -142,6 +164,159 @@ __global__ __launch_bounds__(64 * WPB) void k_conv_mfma(const float* __restrict_
           dst[row * CD + col] = v;
         }
       }
+  }
+}
+
+// ---------------------------------------------------------------- MFMA implicit GEMM, weights through LDS
+// In-kernel stamps on k_conv_mfma (tools/conv_diag.py, 64->64, 82k rows): a wave spends ~13,000 cycles per (tile, offset)
+// unit against 2,048 cycles of MFMA; the time goes into waiting for memory, and the traffic that congests it is the
+// WEIGHT fragments: every wave re-reads the 16 KB slice W_k from L2 for every unit (1.9 GB per launch against 0.46 GB of
+// gathered rows; the 20 waves of a CU sit at different offsets, so the 32 KB L1 holds none of it).
+// Here the WPB waves of a workgroup walk the offsets in lockstep: W_k is copied global -> LDS once per workgroup with
+// global_load_lds_dwordx4 (LDS-DMA: no VGPR staging; the packed weight slice is already the lane-linear LDS image),
+// double-buffered so the copy of W_k+1 is in flight while W_k is multiplied, and every wave reads its B fragments with
+// ds_read_b128.  L2 -> CU weight traffic drops WPB-fold; the source rows are still gathered straight into the A operand
+// registers.  One barrier per offset.  A wave whose 16 rows have no neighbour at k skips its MFMAs but not the barrier.
+// Same summation order per output element as k_conv_mfma (offsets ascending, channels in packed order): identical bits.
+template <int CS, int CD, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_conv_mfma_ls(const float* __restrict__ src, const float* __restrict__ wp,
+                                                           const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
+                                                           int64_t n, const int64_t* d_n, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu,
+                                                           float* __restrict__ dst) {
+  constexpr int NT = CD / 16;
+  constexpr int JG = CS / 16;
+  constexpr int NF = NT * JG;              // 1 KiB fragments per offset
+  __shared__ f32x4 sB[2][NF * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t nlive = spx_live_n(d_n, n);
+  const int64_t row_base = ((int64_t)blockIdx.x * WPB + wave) * 16;
+  const int64_t row = row_base + r;
+  const bool in_range = row < nlive;       // no early return: every wave takes part in the copies and the barriers
+
+#ifdef SPX_CV_DIAG
+  const unsigned long long d_t0 = __builtin_amdgcn_s_memtime(), d_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long d_units = 0;
+#endif
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+  auto copy_w = [&](int k, int buf) {
+#pragma unroll
+    for (int i = 0; i < (NF + WPB - 1) / WPB; ++i) {
+      const int f = wave + i * WPB;       // wave-uniform
+      if (f < NF)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wp4 + ((size_t)k * NF + f) * 64 + lane),
+            (__attribute__((address_space(3))) void*)(&sB[buf][f * 64]), 16, 0, 0);
+    }
+  };
+
+  auto load_id = [&](int k) -> int32_t {
+#ifdef SPX_CV_NO_IDS
+    return (in_range && k < K) ? (int32_t)row : -1;   // diag: no rule-table read, identity gather
+#endif
+    return (in_range && k < K) ? pair[(int64_t)(flip ? K - 1 - k : k) * ld + row] : -1;
+  };
+  auto gather = [&](int32_t id, f32x4 (&a)[JG]) {
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg) {
+      a[jg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef SPX_CV_NO_GATHER
+      if (id >= 0) a[jg] = f32x4{1.f, 2.f, 3.f, (float)id};   // diag: no row read
+#else
+      if (id >= 0) a[jg] = *reinterpret_cast<const f32x4*>(src + (size_t)id * CS + 16 * jg + 4 * q);
+#endif
+    }
+  };
+  // Pipeline: while offset k is multiplied, the rows of offset k+1, the weight slice W_k+1 and the rule entries of
+  // offset k+2 are in flight; the barrier at the top of each trip is the one point where they are waited for.
+  int32_t id_cur = load_id(0);
+  int32_t id_nxt = load_id(1);
+  copy_w(0, 0);
+  f32x4 a_cur[JG], a_nxt[JG];
+  gather(id_cur, a_cur);
+#ifdef SPX_CV_DIAG
+  unsigned long long d_drain = 0, d_bar = 0, d_mma = 0;
+#endif
+  for (int k = 0; k < K; ++k) {
+#ifdef SPX_CV_DIAG
+    unsigned long long d_a = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long d_b = __builtin_amdgcn_s_memtime();
+    d_drain += d_b - d_a;
+#endif
+    __syncthreads();   // W_k landed for every wave, a_cur / id_nxt arrived; buffer (k+1)&1 is free again
+#ifdef SPX_CV_DIAG
+    d_bar += __builtin_amdgcn_s_memtime() - d_b;
+#endif
+    const bool any = __ballot(id_cur >= 0) != 0ull;   // wave-uniform
+    const int32_t id_nn = load_id(k + 2);
+    gather(id_nxt, a_nxt);
+#ifndef SPX_CV_NO_GLDS
+    if (k + 1 < K) copy_w(k + 1, (k + 1) & 1);
+#endif
+    // everything above is only ISSUED here; keep it above the MFMAs (the scheduler would otherwise sink the gathers
+    // next to their use in the next trip and serialise latency and arithmetic again)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef SPX_CV_DIAG
+    unsigned long long d_c = __builtin_amdgcn_s_memtime();
+#endif
+    if (any) {
+#ifdef SPX_CV_DIAG
+      d_units += 1;
+#endif
+      const f32x4* B = sB[k & 1];
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) {
+        f32x4 b[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = B[(nt * JG + jg) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[jg][e], b[nt][e], acc[nt], 0, 0, 0);
+      }
+    }
+#ifdef SPX_CV_DIAG
+    d_mma += __builtin_amdgcn_s_memtime() - d_c;
+#endif
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg) a_cur[jg] = a_nxt[jg];
+    id_cur = id_nxt;
+    id_nxt = id_nn;
+  }
+
+  if (row_base >= nlive) return;
+#ifdef SPX_CV_DIAG
+  if (g_cv_diag && lane == 0) {
+    unsigned long long* o = g_cv_diag + ((size_t)blockIdx.x * WPB + wave) * 4;
+    o[0] = __builtin_amdgcn_s_memtime() - d_t0;
+    o[1] = d_units | ((d_drain >> 6) << 8) | ((d_bar >> 6) << 28) | ((d_mma >> 6) << 48);   // 64-cycle units, 20 bits each
+    o[2] = d_r0;
+    o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = 16 * nt + r;
+    const float sc = scale ? scale[col] : 1.0f;
+    const float sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int64_t orow = row_base + 4 * q + e;
+      if (orow < nlive) {
+        float v = acc[nt][e];
+        if (scale || shift) v = v * sc + sh;
+        if (relu) v = v > 0.f ? v : 0.f;
+        dst[orow * CD + col] = v;
+      }
+    }
   }
 }
 
@@ -215,7 +390,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_cp(const float* __restrict__ 
 #pragma unroll
       for (int jg = 0; jg < JG; ++jg) {
         a_nx[jg] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (has) a_nx[jg] = *reinterpret_cast<const f32x4*>(src + (size_t)sid * CS + q * (CS / 4) + 4 * jg);
+        if (has) a_nx[jg] = *reinterpret_cast<const f32x4*>(src + (size_t)sid * CS + 16 * jg + 4 * q);
       }
     }
     for (int ch = 0; ch < nch; ++ch) {
@@ -229,7 +404,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_cp(const float* __restrict__ 
 #pragma unroll
         for (int jg = 0; jg < JG; ++jg) {
           a_nx[jg] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (has) a_nx[jg] = *reinterpret_cast<const f32x4*>(src + (size_t)sid * CS + q * (CS / 4) + 4 * jg);
+          if (has) a_nx[jg] = *reinterpret_cast<const f32x4*>(src + (size_t)sid * CS + 16 * jg + 4 * q);
         }
       }
       // two independent accumulation chains per column tile (MFMA dependent-issue latency 40 > issue 32 cycles)
@@ -403,7 +578,7 @@ __global__ __launch_bounds__(64 * (CD / 16 / NTW)) void k_conv_mfma_bc(
 #pragma unroll
       for (int jg = 0; jg < JG; ++jg) {
         a[jg] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p < n_k) a[jg] = *reinterpret_cast<const f32x4*>(&s_a[p * LDA + q * (CS / 4) + 4 * jg]);
+        if (p < n_k) a[jg] = *reinterpret_cast<const f32x4*>(&s_a[p * LDA + 16 * jg + 4 * q]);
       }
       f32x4 c0[NTW], c1[NTW];   // two accumulation chains per tile (dependent-issue latency 40 > issue interval 32)
 #pragma unroll
@@ -527,6 +702,27 @@ static int launch_mfma(const float* src, const float* wp, const int32_t* pair, i
       else
         hipLaunchKernelGGL((k_conv_mfma_bc<CS, CD, NTW, 64>), dim3((unsigned)((n + 63) / 64)), dim3(64 * WPT), 0, s, src, wp,
                            pair, ld, K, flip, n, d_n, scale, shift, relu, dst);
+      return SPX_OK;
+    }
+    int use_ls = 0;
+    if (const char* e = getenv("SPX_CONV_LS")) use_ls = atoi(e);  // dev override: weights through LDS, WPB = value
+    if (use_ls && (CS / 16) * (CD / 16) <= 16) {                    // weight slice <= 16 KB: two LDS buffers, 5 waves per SIMD
+      int64_t waves1 = (n + 15) / 16;
+      if (use_ls == 5)
+        hipLaunchKernelGGL((k_conv_mfma_ls<CS, CD, 5>), dim3((unsigned)((waves1 + 4) / 5)), dim3(320), 0, s, src, wp, pair, ld,
+                           K, flip, n, d_n, scale, shift, relu, dst);
+      else if (use_ls == 10)
+        hipLaunchKernelGGL((k_conv_mfma_ls<CS, CD, 10>), dim3((unsigned)((waves1 + 9) / 10)), dim3(640), 0, s, src, wp, pair, ld,
+                           K, flip, n, d_n, scale, shift, relu, dst);
+      else if (use_ls == 8)
+        hipLaunchKernelGGL((k_conv_mfma_ls<CS, CD, 8>), dim3((unsigned)((waves1 + 7) / 8)), dim3(512), 0, s, src, wp, pair, ld,
+                           K, flip, n, d_n, scale, shift, relu, dst);
+      else if (use_ls == 16)
+        hipLaunchKernelGGL((k_conv_mfma_ls<CS, CD, 16>), dim3((unsigned)((waves1 + 15) / 16)), dim3(1024), 0, s, src, wp, pair,
+                           ld, K, flip, n, d_n, scale, shift, relu, dst);
+      else
+        hipLaunchKernelGGL((k_conv_mfma_ls<CS, CD, 4>), dim3((unsigned)((waves1 + 3) / 4)), dim3(256), 0, s, src, wp, pair, ld,
+                           K, flip, n, d_n, scale, shift, relu, dst);
       return SPX_OK;
     }
     int use_cp = 0;
