@@ -100,3 +100,50 @@ def test_reference_voxelresbackbone8x_runs_on_spx():
         assert torch.equal(t["multi_scale_3d_features"][k].features, o["multi_scale_3d_features"][k].features)
     assert torch.equal(t["encoded_spconv_tensor"].features, o["encoded_spconv_tensor"].features)
     assert o["encoded_spconv_tensor"].features.shape[1] == 128
+
+
+def test_reference_unetv2_runs_on_spx():
+    """Row f-3: the reference's UNetV2 source (SparseInverseConv3d, 128->64 SubM, k=1 SparseConv3d) on our operators,
+    against our own UNetV2: same state_dict, bitwise the same outputs."""
+    from oracle.cpu_backend import use_oracle_backend
+    from pcdet_amd.config import AttrDict
+    from pcdet_amd.datasets import SyntheticDataset
+    from pcdet_amd.models.backbones_3d import UNetV2
+    _import_reference_backbone()           # primes the alias packages
+    compat = os.path.join(ROOT, "tsm-det-pointcloud-_amd", "compat")
+    assert compat in sys.path
+    saved = {k: v for k, v in sys.modules.items() if k == "pcdet" or k.startswith("pcdet.")}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        for n in ("pcdet", "pcdet.utils", "pcdet.models", "pcdet.models.backbones_3d"):
+            m = types.ModuleType(n)
+            m.__path__ = [os.path.join(REF, *n.split("."))]
+            sys.modules[n] = m
+        ref_unet = importlib.import_module("pcdet.models.backbones_3d.spconv_unet")
+    finally:
+        for k in [k for k in sys.modules if k == "pcdet" or k.startswith("pcdet.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    ds = SyntheticDataset(cfg_id=0)
+    torch.manual_seed(2)
+    kw = dict(voxel_size=ds.voxel_size, point_cloud_range=ds.point_cloud_range)
+    ours = UNetV2(AttrDict(), 4, ds.grid_size, **kw)
+    theirs = ref_unet.UNetV2(AttrDict(), 4, np.asarray(ds.grid_size), **kw)   # the reference adds [1, 0, 0] to an ndarray
+    assert list(theirs.state_dict().keys()) == list(ours.state_dict().keys())
+    assert [tuple(v.shape) for v in theirs.state_dict().values()] == [tuple(v.shape) for v in ours.state_dict().values()]
+    theirs.load_state_dict(ours.state_dict())
+    ours.eval()
+    theirs.eval()
+    b = ds.collate_batch([ds[0]])
+    with torch.no_grad(), use_oracle_backend():
+        from spx import ops
+        vox = ops.voxelize(torch.from_numpy(b["points"]), ds.point_cloud_range, ds.voxel_size, 5, 16000, batch_size=1,
+                           batch_col=0, xyz_col=1, feat_col=1, want_voxels=False)
+        bd = {"voxel_features": vox["mean"], "voxel_coords": vox["coords"].float(), "batch_size": 1}
+        o, t = ours(dict(bd)), theirs(dict(bd))
+    assert o["point_features"].shape == (vox["coords"].shape[0], 16)
+    assert torch.equal(t["point_features"], o["point_features"])
+    assert torch.equal(t["raw_points_bxyz"], o["raw_points_bxyz"])
+    assert torch.equal(t["encoded_spconv_tensor"].features, o["encoded_spconv_tensor"].features)
+    assert torch.equal(t["encoded_spconv_tensor"].indices, o["encoded_spconv_tensor"].indices)

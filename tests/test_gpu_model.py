@@ -345,6 +345,46 @@ def test_res_backbone_forward_backward_parity():
         assert _rel(p.grad, q.grad) < 1e-3, n
 
 
+def test_unetv2_forward_backward_parity():
+    """Row f-3: UNetV2 encoder-decoder (SparseInverseConv3d, 128->64 SubM, k=1 SparseConv3d, residual blocks) HIP vs oracle
+    backend: point-wise features, the detection-branch tensor and every parameter gradient."""
+    from oracle.cpu_backend import use_oracle_backend
+    from pcdet_amd.config import AttrDict
+    from pcdet_amd.datasets import SyntheticDataset
+    from pcdet_amd.models.backbones_3d import UNetV2
+    ds = SyntheticDataset(cfg_id=0)
+    torch.manual_seed(4)
+    net = UNetV2(AttrDict(), 4, ds.grid_size, voxel_size=ds.voxel_size, point_cloud_range=ds.point_cloud_range)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.eval()          # running statistics: keeps the comparison free of batch-statistics feedback
+    ref = copy.deepcopy(net)
+    b = _batch(ds)
+
+    def run(model, dev):
+        from spx import ops
+        vox = ops.voxelize(b["points"].to(dev), ds.point_cloud_range, ds.voxel_size, 5, 16000, batch_size=2, batch_col=0,
+                           xyz_col=1, feat_col=1, want_voxels=False)
+        out = model({"voxel_features": vox["mean"], "voxel_coords": vox["coords"], "batch_size": 2})
+        f, e = out["point_features"], out["encoded_spconv_tensor"].features
+        assert f.shape == (vox["coords"].shape[0], 16) and out["raw_points_bxyz"].shape == (f.shape[0], 4)
+        loss = (f * torch.linspace(-1, 1, f.numel(), device=f.device).view_as(f)).sum() + \
+               (e * torch.linspace(1, -1, e.numel(), device=e.device).view_as(e)).sum()
+        loss.backward()
+        return f, e, out["raw_points_bxyz"]
+
+    with use_oracle_backend():
+        fc, ec, pc = run(ref, torch.device("cpu"))
+    dev = torch.device("cuda:0")
+    net.to(dev)
+    fg, eg, pg = run(net, dev)
+    assert torch.equal(pg.cpu(), pc)
+    assert _rel(fg, fc) < 1e-4 and _rel(eg, ec) < 1e-4
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and _rel(p.grad, q.grad) < 1e-3, n
+
+
 def test_graphed_static_capacity_forward_matches_dynamic():
     """Sync-free, hipGraph-captured forward (device-side row counts, static capacities) against the ordinary dynamic
     forward: identical kernels on identical rows => bitwise identical sparse outputs, across replays with different

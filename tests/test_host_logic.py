@@ -64,7 +64,7 @@ def test_registries_and_unknown_modules():
     from pcdet_amd.config import AttrDict, cfg_from_yaml_file
     from pcdet_amd.datasets import SyntheticDataset
     from pcdet_amd.models import backbones_3d, build_network
-    assert set(backbones_3d.__all__) == {"VoxelBackBone8x", "VoxelResBackBone8x"}
+    assert set(backbones_3d.__all__) == {"VoxelBackBone8x", "VoxelResBackBone8x", "UNetV2"}
     cfg = cfg_from_yaml_file(os.path.join(CFG, "kitti_models", "second.yaml"), AttrDict())
     ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, True, cfg_id=0)
     cfg.MODEL.BACKBONE_3D.NAME = "VoxelResBackBone8x"
