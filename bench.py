@@ -169,7 +169,8 @@ class KernelTimer(object):
             P = t._P(pair, n_dst)
             flops = 2.0 * P * cs * c_dst
             nbytes = 4.0 * (src.shape[0] * cs + n_dst * c_dst + kvol * cs * c_dst + kvol * n_dst)
-            fam = "conv_gemm[mfma]" if (cs % 16 == 0 and c_dst % 16 == 0) else "conv_gemm[valu]"
+            # one family per template instantiation, named so that it maps 1:1 to a rocprofv3 row (k_conv_mfma<cs, cd, ..>)
+            fam = "conv_gemm[mfma %dx%d]" % (cs, c_dst) if (cs % 16 == 0 and c_dst % 16 == 0) else "conv_gemm[valu]"
             return t._timed(fam, flops, nbytes, sv["conv_gemm"], src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k,
                             scale, shift, relu, d_n_dst)
 
@@ -270,9 +271,16 @@ def roofline_of(fam):
         ach, peak, unit, bound = d["flops"] / t / 1e12, MFMA_F32_PEAK / 1e12, "TFLOP/s", "mfma"
     else:
         ach, peak, unit, bound = d["bytes"] / t / 1e9, HBM_PEAK / 1e9, "GB/s", "hbm"
-    return {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+    rocprof_name = "?"
+    if name.startswith("conv_gemm[mfma "):
+        cs, cd = name[len("conv_gemm[mfma "):-1].split("x")
+        rocprof_name = "k_conv_mfma<%s, %s," % (cs, cd)
+    elif name == "conv_wgrad":
+        rocprof_name = "k_wgrad_mfma"
+    return {"kernel": name, "rocprof_kernel": rocprof_name + (" ...>" if rocprof_name.endswith(",") else ""),
+            "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
             "frac": round(ach / peak, 4),
-            "traffic": pmc_traffic({"conv_gemm[mfma]": "k_conv_mfma", "conv_wgrad": "k_wgrad_mfma"}.get(name, "?")),
+            "traffic": pmc_traffic(rocprof_name),
             "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches_per_step"],
             "algorithmic_flops_per_launch": d["flops"] / d["launches"],
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"]}
@@ -332,7 +340,7 @@ def main():
     cfg, ds, model, optimizer, sched = build(args.cfg, device, args.dense_dtype)
     model.train(args.mode == "train")
     if world > 1 and args.mode == "train":
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=32,
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=8,
                                                           gradient_as_bucket_view=True, broadcast_buffers=False)
     batches = make_batches(ds, args.cfg, batch, rank, device)
     step = Step(model, optimizer, sched, cfg.OPTIMIZATION.GRAD_NORM_CLIP, args.mode, args.dense_dtype)
