@@ -153,6 +153,20 @@ int spx_conv_gemm(const float *src, int c_src, const float *w_packed, int c_dst,
                   const int32_t *pair, int64_t pair_ld, int64_t n_dst, const int64_t *d_n_dst,
                   const float *scale, const float *shift, int relu, float *dst, spx_stream_t stream);
 
+/* MFMA-work-balanced schedule of the same product (csrc/conv_balanced.hip): spx_conv_plan counts the non-empty
+ * (16-row tile, offset) units of a rule table once and cuts them into equal ranges for a persistent grid; the plan
+ * depends only on (pair, n_dst), so it is reused by every convolution that reads the table (forward, dgrad with
+ * flip_k, the second layer of a submanifold pair).  spx_conv_gemm_balanced = spx_conv_gemm under that schedule;
+ * returns SPX_ERR_UNSUPPORTED for channel pairs it does not cover (use spx_conv_gemm).  Same reference call sites. */
+size_t spx_conv_plan_bytes(int64_t n_dst);
+int spx_conv_plan(const int32_t *pair, int64_t pair_ld, int kvol, int64_t n_dst, const int64_t *d_n_dst, int32_t *plan,
+                  spx_stream_t stream);
+size_t spx_conv_gemm_balanced_ws_bytes(int c_dst, int64_t n_dst);
+int spx_conv_gemm_balanced(const float *src, int c_src, const float *w_packed, int c_dst, int kvol, int flip_k,
+                           const int32_t *pair, int64_t pair_ld, int64_t n_dst, const int64_t *d_n_dst,
+                           const float *scale, const float *shift, int relu, const int32_t *plan, float *dst, void *ws,
+                           size_t ws_bytes, spx_stream_t stream);
+
 size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n_out);
 int spx_conv_wgrad(const float *in, int cin, const float *dout, int cout, int kvol, const int32_t *pair,
                    int64_t pair_ld, int64_t n_out, const int64_t *d_n_out, float *dw, void *ws, size_t ws_bytes,

@@ -246,6 +246,46 @@ def test_conv_full_size_linearity_and_oracle(orc):
     assert torch.equal(dw, ops.conv_wgrad(x, dout, rb.pair, rb.ld, rb.n_out, tuple(w.shape)))
 
 
+def test_conv_balanced_schedule_matches_tile_per_wave(orc):
+    """spx_conv_gemm_balanced (persistent grid, equal MFMA work per wave, cut tiles summed head + tail by the fix-up
+    kernel) against spx_conv_gemm on the same tables: forward, flipped (dgrad of a submanifold conv), strided tables in
+    both directions, with and without the fused epilogue; bitwise reproducible from launch to launch."""
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, 2, 4)
+    dev = _dev()
+    d_idx = torch.from_numpy(idx_np).to(dev)
+    g = torch.Generator().manual_seed(11)
+    sub = ops.subm_rulebook(d_idx, 4, shape, (3, 3, 3))
+    strd = ops.conv_rulebook(d_idx, 4, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    cases = [(sub.pair, sub.ld, sub.n_out, sub.n_in, False), (sub.pair, sub.ld, sub.n_in, sub.n_out, True),
+             (strd.pair, strd.ld, strd.n_out, strd.n_in, False),
+             (strd.pair_bwd, strd.pair_bwd.shape[1], strd.n_in, strd.n_out, False)]
+    for (cs, cd) in ((64, 64), (32, 64), (64, 32), (32, 32)):
+        w = (torch.randn(cd, 3, 3, 3, cs, generator=g) / np.sqrt(27 * cs)).to(dev)
+        wp = ops.pack_weight(w, 0)
+        for pair, ld, n_dst, n_src, flip in cases:
+            x = torch.randn(n_src, cs, generator=g).to(dev)
+            plan = ops.conv_plan(pair, ld, 27, n_dst)
+            hdr = plan[:4].cpu().numpy()
+            assert 1 <= hdr[0] <= 3072 and hdr[1] >= 27 * hdr[0] and hdr[2] == (n_dst + 15) // 16
+            ref = ops.conv_gemm(x, wp, cd, 27, pair, ld, n_dst, flip_k=flip)
+            out = ops.conv_gemm_balanced(x, wp, cd, 27, pair, ld, n_dst, plan, flip_k=flip)
+            assert _rel_t(out, ref) < 2e-6
+            assert torch.equal(out, ops.conv_gemm_balanced(x, wp, cd, 27, pair, ld, n_dst, plan, flip_k=flip))
+        sc = (torch.rand(cd, generator=g) + 0.5).to(dev)
+        sh = torch.randn(cd, generator=g).to(dev)
+        pair, ld, n_dst, n_src, flip = cases[0]
+        x = torch.randn(n_src, cs, generator=g).to(dev)
+        plan = ops.conv_plan(pair, ld, 27, n_dst)
+        ref = ops.conv_gemm(x, wp, cd, 27, pair, ld, n_dst, scale=sc, shift=sh, relu=True)
+        out = ops.conv_gemm_balanced(x, wp, cd, 27, pair, ld, n_dst, plan, scale=sc, shift=sh, relu=True)
+        assert _rel_t(out, ref) < 2e-6 and float(out.min()) >= 0.0
+
+
+def _rel_t(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12))
+
+
 # ------------------------------------------------------------------------------------------ densify
 
 @pytest.mark.parametrize("channels_last", [False, True])

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--what", default="fwd,dgrad,wgrad,rulebook")
     ap.add_argument("--layers", default="")
+    ap.add_argument("--balanced", action="store_true", help="fwd/dgrad through the balanced persistent schedule")
     args = ap.parse_args()
     what = args.what.split(",")
     dev = torch.device("cuda:0")
@@ -89,13 +90,23 @@ def main():
         nbytes = 4.0 * (rb.n_in * cin + rb.n_out * cout + K * cin * cout + K * rb.n_out)
         line = "%-12s %3d->%3d %-6s n_in %7d n_out %7d P %8d (%.1f/row)" % (name, cin, cout, ctype, rb.n_in, rb.n_out,
                                                                               P, P / max(rb.n_out, 1))
+        bal_f = args.balanced and ops.balanced_ok(cin, cout, rb.n_out)
+        bal_b = args.balanced and ops.balanced_ok(cout, cin, rb.n_in)
         if "fwd" in what:
-            t = timeit(lambda: ops.conv_gemm(x, wp, cout, K, rb.pair, rb.ld, rb.n_out), args.iters)
+            if bal_f:
+                plan = ops.conv_plan(rb.pair, rb.ld, K, rb.n_out)
+                t = timeit(lambda: ops.conv_gemm_balanced(x, wp, cout, K, rb.pair, rb.ld, rb.n_out, plan), args.iters)
+            else:
+                t = timeit(lambda: ops.conv_gemm(x, wp, cout, K, rb.pair, rb.ld, rb.n_out), args.iters)
             tot["fwd"] += t
             tot["flops"] += flops
             line += " | fwd %7.1f us %6.2f TF/s %6.0f GB/s" % (t * 1e6, flops / t / 1e12, nbytes / t / 1e9)
         if "dgrad" in what and cin >= 16:
-            if rb.subm:
+            if bal_b:
+                tb, ldb = (rb.pair, rb.ld) if rb.subm else (rb.pair_bwd, rb.pair_bwd.shape[1])
+                planb = ops.conv_plan(tb, ldb, K, rb.n_in)
+                f = (lambda: ops.conv_gemm_balanced(dout, wt, cin, K, tb, ldb, rb.n_in, planb, flip_k=rb.subm))
+            elif rb.subm:
                 f = (lambda: ops.conv_gemm(dout, wt, cin, K, rb.pair, rb.ld, rb.n_in, flip_k=True))
             else:
                 f = (lambda: ops.conv_gemm(dout, wt, cin, K, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in))

@@ -30,6 +30,18 @@ def _packed(weight, mode):
     return wp
 
 
+def _conv(src, wp, c_dst, kvol, pair, ld, n_dst, flip, scale, shift, relu, d_n, rb):
+    """One gather-GEMM launch: the MFMA-work-balanced persistent schedule where it applies (plan cached on the rulebook),
+    the one-tile-per-wave kernel otherwise."""
+    if (rb is not None and src.is_cuda and n_dst > 0 and src.shape[0] > 0
+            and ops.balanced_ok(src.shape[1], c_dst, n_dst)):
+        plan = ops.plan_for(rb, pair, ld, kvol, n_dst, d_n)
+        return ops.conv_gemm_balanced(src, wp, c_dst, kvol, pair, ld, n_dst, plan, flip_k=flip, scale=scale, shift=shift,
+                                      relu=relu, d_n_dst=d_n)
+    return ops.conv_gemm(src, wp, c_dst, kvol, pair, ld, n_dst, flip_k=flip, scale=scale, shift=shift, relu=relu,
+                         d_n_dst=d_n)
+
+
 class _SparseConvFn(torch.autograd.Function):
     """out = gather(src, pair_f) (*) W   — one sparse conv application.
 
@@ -38,14 +50,15 @@ class _SparseConvFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, feats, weight, bias, pair_f, ld_f, n_dst, pair_b, ld_b, flip_b, scale, shift, relu, d_n=None):
+    def forward(ctx, feats, weight, bias, pair_f, ld_f, n_dst, pair_b, ld_b, flip_b, scale, shift, relu, d_n=None,
+                rb=None, d_n_src=None):
         cout, cin = weight.shape[0], weight.shape[-1]
         kvol = weight.numel() // (cout * cin)
         wp = _packed(weight, 0)
         sh = shift if shift is not None else bias
-        out = ops.conv_gemm(feats, wp, cout, kvol, pair_f, ld_f, n_dst, flip_k=False, scale=scale, shift=sh, relu=relu,
-                            d_n_dst=d_n)
+        out = _conv(feats, wp, cout, kvol, pair_f, ld_f, n_dst, False, scale, sh, relu, d_n, rb)
         ctx.save_for_backward(feats, weight)
+        ctx.rb, ctx.d_n_src = rb, d_n_src
         ctx.tables = (pair_f, ld_f, n_dst, pair_b, ld_b, flip_b)
         ctx.has_bias = bias is not None
         ctx.fused = scale is not None or shift is not None or relu
@@ -63,12 +76,12 @@ class _SparseConvFn(torch.autograd.Function):
         dfe = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = ops.pack_weight(weight, 1)
-            dfe = ops.conv_gemm(dout, wt, cin, kvol, pair_b, ld_b, feats.shape[0], flip_k=flip_b)
+            dfe = _conv(dout, wt, cin, kvol, pair_b, ld_b, feats.shape[0], flip_b, None, None, False, ctx.d_n_src, ctx.rb)
         if ctx.needs_input_grad[1]:
             dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dout.sum(0)
-        return dfe, dw, db, None, None, None, None, None, None, None, None, None, None
+        return dfe, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def sparse_conv(feats, weight, bias, rb, inverse=False, scale=None, shift=None, relu=False):
@@ -77,12 +90,12 @@ def sparse_conv(feats, weight, bias, rb, inverse=False, scale=None, shift=None, 
     if not inverse:
         if rb.subm:
             return _SparseConvFn.apply(feats, weight, bias, rb.pair, rb.ld, rb.n_out, rb.pair, rb.ld, True, scale,
-                                       shift, relu, rb.d_n_out)
+                                       shift, relu, rb.d_n_out, rb, rb.d_n_in)
         return _SparseConvFn.apply(feats, weight, bias, rb.pair, rb.ld, rb.n_out, rb.pair_bwd, rb.pair_bwd.shape[1],
-                                   False, scale, shift, relu, rb.d_n_out)
+                                   False, scale, shift, relu, rb.d_n_out, rb, rb.d_n_in)
     assert not rb.subm and rb.pair_bwd is not None
     return _SparseConvFn.apply(feats, weight, bias, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in, rb.pair, rb.ld, False,
-                               scale, shift, relu, rb.d_n_in)
+                               scale, shift, relu, rb.d_n_in, rb, rb.d_n_out)
 
 
 class _DenseFn(torch.autograd.Function):

@@ -4,6 +4,7 @@ Every function here launches HIP kernels from libspx.so on torch's current strea
 torch ops and there is no CPU path (inputs must live on a GPU).
 """
 import ctypes
+import os
 
 import torch
 
@@ -54,6 +55,7 @@ class Rulebook(object):
                  ksize=None, stride=None, padding=None, dilation=None):
         self.pair, self.ld, self.n_in, self.n_out, self.kvol, self.subm = pair, ld, n_in, n_out, kvol, subm
         self.out_indices, self.out_shape, self.in_shape = out_indices, list(out_shape), list(in_shape)
+        self._plans = {}
         self.pair_bwd, self.cnt = pair_bwd, cnt
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
         # static-capacity (graph) mode: live row counts stay on the device, n_in / n_out above are CAPACITIES
@@ -199,6 +201,50 @@ def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=N
     check(lib.spx_conv_gemm(_ptr(src), src.shape[1], _ptr(w_packed), c_dst, kvol, int(bool(flip_k)), _ptr(pair), ld,
                             n_dst, _ptr(d_n_dst), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(dst), _stream(src)),
           "spx_conv_gemm")
+    return dst
+
+
+_BALANCED_SHAPES = {(32, 64), (64, 32), (64, 64)}   # 32x32 measured slower (weight-bandwidth bound either way)
+# below this many destination rows the plan / fix-up launches cost more than the balanced schedule saves
+_BALANCED_MIN_ROWS = int(os.environ.get("SPX_CONV_BALANCED_MIN_ROWS", "24000"))
+_BALANCED = os.environ.get("SPX_CONV_BALANCED", "1") != "0"
+
+
+def conv_plan(pair, ld, kvol, n_dst, d_n_dst=None):
+    """Work plan of the balanced schedule for one rule table (include/spx.h: spx_conv_plan); int32 device tensor."""
+    _need_gpu(pair)
+    lib = _lib.load()
+    plan = torch.empty((lib.spx_conv_plan_bytes(n_dst) // 4,), dtype=torch.int32, device=pair.device)
+    check(lib.spx_conv_plan(_ptr(pair), ld, kvol, n_dst, _ptr(d_n_dst), _ptr(plan), _stream(pair)), "spx_conv_plan")
+    return plan
+
+
+def plan_for(rb, pair, ld, kvol, n_dst, d_n_dst=None):
+    """Plan of rule table `pair`, built once per Rulebook and table (forward, dgrad and sibling layers share it)."""
+    key = (pair.data_ptr(), int(n_dst))
+    plan = rb._plans.get(key)
+    if plan is None:
+        plan = rb._plans[key] = conv_plan(pair, ld, kvol, n_dst, d_n_dst)
+    return plan
+
+
+def balanced_ok(c_src, c_dst, n_dst):
+    return _BALANCED and (c_src, c_dst) in _BALANCED_SHAPES and n_dst >= _BALANCED_MIN_ROWS
+
+
+def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k=False, scale=None, shift=None,
+                       relu=False, d_n_dst=None):
+    """conv_gemm under the MFMA-work-balanced persistent schedule (`plan` from conv_plan on the same table / n_dst)."""
+    _need_gpu(src, w_packed, pair, plan)
+    lib = _lib.load()
+    src = src.contiguous()
+    assert src.dtype == torch.float32 and n_dst > 0 and src.shape[0] > 0
+    dst = torch.empty((n_dst, c_dst), dtype=torch.float32, device=src.device)
+    wsb = lib.spx_conv_gemm_balanced_ws_bytes(c_dst, n_dst)
+    ws = workspace(src.device, wsb)
+    check(lib.spx_conv_gemm_balanced(_ptr(src), src.shape[1], _ptr(w_packed), c_dst, kvol, int(bool(flip_k)), _ptr(pair),
+                                     ld, n_dst, _ptr(d_n_dst), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(plan),
+                                     _ptr(dst), _ptr(ws), wsb, _stream(src)), "spx_conv_gemm_balanced")
     return dst
 
 
