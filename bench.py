@@ -158,8 +158,8 @@ class KernelTimer(object):
     def install(self):
         from spx import ops
         t = self
-        names = ["conv_gemm", "conv_wgrad", "subm_rulebook", "conv_rulebook", "voxelize", "densify", "densify_bwd",
-                 "pack_weight"]
+        names = ["conv_gemm", "conv_gemm_balanced", "conv_plan", "conv_wgrad", "subm_rulebook", "conv_rulebook", "voxelize",
+                 "densify", "densify_bwd", "pack_weight"]
         self._saved = {n: getattr(ops, n) for n in names}
         sv = self._saved
 
@@ -173,6 +173,18 @@ class KernelTimer(object):
             fam = "conv_gemm[mfma %dx%d]" % (cs, c_dst) if (cs % 16 == 0 and c_dst % 16 == 0) else "conv_gemm[valu]"
             return t._timed(fam, flops, nbytes, sv["conv_gemm"], src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k,
                             scale, shift, relu, d_n_dst)
+
+        def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k=False, scale=None, shift=None,
+                               relu=False, d_n_dst=None):
+            P = t._P(pair, n_dst)
+            cs = src.shape[1]
+            flops = 2.0 * P * cs * c_dst
+            nbytes = 4.0 * (src.shape[0] * cs + n_dst * c_dst + kvol * cs * c_dst + kvol * n_dst)
+            return t._timed("conv_gemm[mfma %dx%d balanced]" % (cs, c_dst), flops, nbytes, sv["conv_gemm_balanced"], src, w_packed,
+                            c_dst, kvol, pair, ld, n_dst, plan, flip_k, scale, shift, relu, d_n_dst)
+
+        def conv_plan(pair, ld, kvol, n_dst, d_n_dst=None):
+            return t._timed("conv_plan", 0.0, 4.0 * kvol * n_dst, sv["conv_plan"], pair, ld, kvol, n_dst, d_n_dst)
 
         def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
             cout, cin = wshape[0], wshape[-1]
@@ -221,7 +233,8 @@ class KernelTimer(object):
         def pack_weight(weight, mode):
             return t._timed("pack_weight", 0.0, 8.0 * weight.numel(), sv["pack_weight"], weight, mode)
 
-        for n, f in dict(conv_gemm=conv_gemm, conv_wgrad=conv_wgrad, subm_rulebook=subm_rulebook,
+        for n, f in dict(conv_gemm=conv_gemm, conv_gemm_balanced=conv_gemm_balanced, conv_plan=conv_plan,
+                         conv_wgrad=conv_wgrad, subm_rulebook=subm_rulebook,
                          conv_rulebook=conv_rulebook, voxelize=voxelize, densify=densify, densify_bwd=densify_bwd,
                          pack_weight=pack_weight).items():
             setattr(ops, n, f)
@@ -272,7 +285,10 @@ def roofline_of(fam):
     else:
         ach, peak, unit, bound = d["bytes"] / t / 1e9, HBM_PEAK / 1e9, "GB/s", "hbm"
     rocprof_name = "?"
-    if name.startswith("conv_gemm[mfma "):
+    if name.startswith("conv_gemm[mfma ") and name.endswith(" balanced]"):
+        cs, cd = name[len("conv_gemm[mfma "):-len(" balanced]")].split("x")
+        rocprof_name = "k_conv_mfma_pbl<%s, %s>" % (cs, cd)      # event time also covers its k_conv_fixup (~6 us)
+    elif name.startswith("conv_gemm[mfma "):
         cs, cd = name[len("conv_gemm[mfma "):-1].split("x")
         rocprof_name = "k_conv_mfma<%s, %s," % (cs, cd)
     elif name == "conv_wgrad":

@@ -1,18 +1,22 @@
-// conv_balanced.hip — sparse convolution forward / dgrad with an MFMA-work-balanced, persistent schedule.
+// conv_balanced.hip — sparse convolution forward / dgrad with an MFMA-work-balanced, persistent, block-lockstep schedule.
 //
 // Same arithmetic as conv_gemm.hip (output-stationary implicit GEMM, v_mfma_f32_16x16x4_f32, same packed weights, same
-// gather map).  What changes is WHO does which work.  In-kernel stamps on k_conv_mfma (tools/conv_diag.py) showed that a
-// launch of one 16-row tile per wave ends with a long low-occupancy tail: ~5 tiles per SIMD, tiles differ in their
-// number of non-empty offsets ("units"), a wave left alone on its SIMD keeps the MFMA pipe only 33-50 % busy, and the
-// launch takes twice its MFMA floor.  Here
-//   1. spx_conv_plan counts the units of every tile (a 27-bit mask per tile), prefix-sums them, and cuts the flat list
-//      of all units into W equal ranges, W = the number of wave slots of the chip (<= U / K so that a tile is cut at
-//      most once);
-//   2. k_conv_mfma_pb runs exactly one wave per slot; wave w walks the tiles of its unit range; a tile that lies
-//      entirely inside the range is written to `dst` directly, the (at most two) cut tiles at its ends go to a scratch
-//      buffer as partial sums;
-//   3. k_conv_fixup adds the two partial sums of every cut tile (head part + tail part, a fixed order) and applies the
-//      epilogue.  No atomics, no in-kernel hand-off: results are bitwise reproducible from run to run.
+// gather map).  What changes is WHO does which work and where the weights come from.  In-kernel stamps on k_conv_mfma
+// (tools/conv_diag.py) showed (a) a wave waiting out five memory round trips per (tile, offset) unit, ~14,000 cycles
+// against 2,048 of MFMA, (b) 1.9 GB of weight fragments moving L2 -> CU per 64x64 launch (every wave re-reads the
+// 16 KB slice W_k per unit), and (c) a launch that ends in a long low-occupancy tail because tiles differ in their
+// number of non-empty offsets.  Here
+//   1. spx_conv_plan records a 27-bit offset mask per 16-row tile, counts the non-empty (64-row super-tile, offset)
+//      super-units, prefix-sums them and deals the flat list in equal ranges to a persistent grid of workgroups
+//      (4 per CU);
+//   2. k_conv_mfma_pbl: the four waves of a workgroup hold the accumulators of the four 16-row tiles of a super-tile and
+//      walk the workgroup's super-units in lockstep: W_k is copied global -> LDS once per workgroup and super-unit
+//      (global_load_lds_dwordx4, double buffered, in flight while the previous super-unit is multiplied), the rows of
+//      the next super-unit are gathered and the rule entries of the one after are read meanwhile; one barrier per
+//      super-unit.  A super-tile whose offsets all belong to one workgroup is written to `dst` directly; one shared with
+//      neighbouring workgroups goes to a scratch slot as a partial sum;
+//   3. k_conv_fixup adds the partial sums of every shared super-tile in workgroup order (= offset order, a fixed order)
+//      and applies the epilogue.  No atomics, no in-kernel hand-off: results are bitwise reproducible from run to run.
 // The plan depends only on the rule table, so the python layer caches it per rulebook (forward, dgrad and the second
 // layer of a submanifold pair all reuse it).
 //
@@ -25,21 +29,24 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kWaves = 3072;        // wave slots used: 3 per SIMD (256 CUs x 4 SIMDs); the 64x64 kernel holds a whole
-                                    // unit's weight fragments (64 VGPRs) + two row sets in registers (160 VGPRs)
-constexpr int kHdr = 4;             // plan header: [0] active waves nw, [1] total units U, [2] tiles T, [3] reserved
+constexpr int kBlocks = 1024;       // persistent workgroups: 4 per CU (256 CUs), 4 waves each = 4 waves per SIMD
+constexpr int kLdsPerBlock = 36 * 1024;   // LDS footprint forced per workgroup: four fit a CU's 160 KiB, a fifth not
+constexpr int kPreLds = 12 * 1024;  // prefix entries staged in LDS by the plan kernel (786k rows)
+constexpr int kHdr = 4;             // plan header: [0] active workgroups nb, [1] super-units U, [2] super-tiles T4, [3] -
 
-// plan layout (int32): hdr[kHdr] | wstart[kWaves + 1] | mask[Tcap] | pre[Tcap + 1] | split[Tcap]
+// plan layout (int32): hdr[kHdr] | wstart[kBlocks + 1, padded] | mask[4 * T4cap] | pre4[T4cap + 1]
 __host__ __device__ inline int64_t plan_off_wstart() { return kHdr; }
-__host__ __device__ inline int64_t plan_off_mask() { return kHdr + kWaves + 1; }
-__host__ __device__ inline int64_t plan_off_pre(int64_t tcap) { return plan_off_mask() + tcap; }
-__host__ __device__ inline int64_t plan_off_split(int64_t tcap) { return plan_off_pre(tcap) + tcap + 1; }
-__host__ __device__ inline int64_t plan_ints(int64_t tcap) { return plan_off_split(tcap) + tcap; }
+__host__ __device__ inline int64_t plan_off_mask() { return kHdr + (kBlocks + 1 + 3) / 4 * 4; }   // 16-byte aligned
+__host__ __device__ inline int64_t plan_off_pre(int64_t t4cap) { return plan_off_mask() + 4 * t4cap; }
+__host__ __device__ inline int64_t plan_ints(int64_t t4cap) { return plan_off_pre(t4cap) + t4cap + 1; }
 
-// ---------------------------------------------------------------- plan, pass 1: unit mask per tile
+// first super-unit of workgroup b when U super-units are dealt to nb workgroups
+__device__ __forceinline__ int block_u0(int b, int U, int nb) { return (int)((int64_t)b * U / nb); }
+
+// ---------------------------------------------------------------- plan, pass 1: offset mask per 16-row tile
 // One wave looks at 4 tiles (lane = 16*sub + r): bit k of mask[t] = some row of tile t has a neighbour at table row k.
 __global__ __launch_bounds__(256) void k_plan_mask(const int32_t* __restrict__ pair, int64_t ld, int K, int64_t n,
-                                                   const int64_t* d_n, int64_t tcap, int32_t* __restrict__ plan) {
+                                                   const int64_t* d_n, int64_t t4cap, int32_t* __restrict__ plan) {
   const int lane = threadIdx.x & 63, sub = lane >> 4, r = lane & 15;
   const int64_t nlive = spx_live_n(d_n, n);
   const int64_t T = (nlive + 15) / 16;
@@ -57,236 +64,283 @@ __global__ __launch_bounds__(256) void k_plan_mask(const int32_t* __restrict__ p
       if ((b >> (16 * sub)) & 0xFFFFull) m |= 1u << (k0 + u);
     }
   }
-  if (r == 0 && tile < tcap) plan[plan_off_mask() + tile] = tile < T ? (int32_t)m : 0;
+  if (r == 0 && tile < 4 * t4cap) plan[plan_off_mask() + tile] = tile < T ? (int32_t)m : 0;
 }
 
-// ---------------------------------------------------------------- plan, pass 2 (one block): prefix, cuts, split flags
-__global__ __launch_bounds__(1024) void k_plan_scan(int K, int64_t n, const int64_t* d_n, int64_t tcap,
-                                                    int32_t* __restrict__ plan) {
-  __shared__ int s_part[1024];
-  __shared__ int s_total;
-  const int tid = threadIdx.x;
+// ---------------------------------------------------------------- plan, pass 2 (one block): prefix over super-tiles, cuts
+__global__ __launch_bounds__(1024) void k_plan_scan(int64_t n, const int64_t* d_n, int64_t t4cap, int32_t* __restrict__ plan) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t nlive = spx_live_n(d_n, n);
-  const int T = (int)((nlive + 15) / 16);
+  const int T4 = (int)((nlive + 63) / 64);
   const int32_t* mask = plan + plan_off_mask();
-  int32_t* pre = plan + plan_off_pre(tcap);
-  int32_t* split = plan + plan_off_split(tcap);
+  int32_t* pre = plan + plan_off_pre(t4cap);
   int32_t* wstart = plan + plan_off_wstart();
-  // exclusive prefix of popcount(mask) over tiles: each thread owns a contiguous chunk
-  const int per = (T + 1023) / 1024;
-  const int lo = tid * per, hi = lo + per < T ? lo + per : T;
-  int sum = 0;
-  for (int t = lo; t < hi; ++t) sum += __popc((unsigned)mask[t]);
-  s_part[tid] = sum;
+  if (tid == 0) s_carry = 0;
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int i = 0; i < 1024; ++i) {
-      int v = s_part[i];
-      s_part[i] = run;
-      run += v;
+  for (int base = 0; base < T4; base += 1024) {          // block-wide exclusive scan, 1024 super-tiles per trip
+    const int S = base + tid;
+    int v = 0;
+    if (S < T4) {
+      const int4 m = *reinterpret_cast<const int4*>(mask + 4 * (size_t)S);
+      v = __popc((unsigned)(m.x | m.y | m.z | m.w));     // super-units: offsets present in any of the four tiles
     }
-    s_total = run;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int off = s_carry;
+    for (int i = 0; i < wv; ++i) off += s_wave[i];
+    if (S < T4) pre[S] = off + incl - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = off + incl;
+    __syncthreads();
   }
-  __syncthreads();
-  int run = s_part[tid];
-  for (int t = lo; t < hi; ++t) {
-    pre[t] = run;
-    run += __popc((unsigned)mask[t]);
-    split[t] = 0;
-  }
-  const int U = s_total;
+  const int U = s_carry;
   if (tid == 0) {
-    pre[T] = U;
-    int nw = U / (K > 0 ? K : 1);
-    if (nw > kWaves) nw = kWaves;
-    if (nw < 1) nw = U > 0 ? 1 : 0;
-    plan[0] = nw;
+    pre[T4] = U;
+    int nb = U / 8;                       // at least 8 super-units per workgroup
+    if (nb > kBlocks) nb = kBlocks;
+    if (nb < 1) nb = U > 0 ? 1 : 0;
+    plan[0] = nb;
     plan[1] = U;
-    plan[2] = T;
+    plan[2] = T4;
     plan[3] = 0;
   }
-  __syncthreads();   // pre[], split[] written by this block are visible to it after the barrier
-  const int nw = plan[0];
-  // wave w owns units [w*U/nw, (w+1)*U/nw); wstart[w] = first tile with pre[t+1] > u0 (the tile holding unit u0)
-  for (int w = tid; w <= kWaves; w += 1024) {
-    int t0 = T;
-    if (w < nw) {
-      const int u0 = (int)((int64_t)w * U / nw);
-      int a = 0, b = T;                        // smallest t in [0, T) with pre[t + 1] > u0
-      while (a < b) {
-        int mid = (a + b) >> 1;
-        if (pre[mid + 1] > u0) b = mid; else a = mid + 1;
+  __syncthreads();
+  const int nb = plan[0];
+  // wstart[b] = the super-tile that holds super-unit u0(b): smallest S with pre[S + 1] > u0.  The searches read the
+  // prefix from LDS when it fits (11 dependent reads each: from L2 they were most of this kernel's 20 us).
+  __shared__ int s_pre[kPreLds];
+  const bool in_lds = T4 + 1 <= kPreLds;
+  if (in_lds)
+    for (int i = tid; i <= T4; i += 1024) s_pre[i] = pre[i];
+  __syncthreads();
+  for (int b = tid; b <= kBlocks; b += 1024) {
+    int s0 = T4;
+    if (b < nb) {
+      const int u0 = block_u0(b, U, nb);
+      int lo = 0, hi = T4;
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        const int v = in_lds ? s_pre[mid + 1] : pre[mid + 1];
+        if (v > u0) hi = mid; else lo = mid + 1;
       }
-      t0 = a;
-      if (w > 0 && u0 > pre[t0]) split[t0] = 1;   // the cut falls strictly inside tile t0
+      s0 = lo;
     }
-    wstart[w] = t0;
+    wstart[b] = s0;
   }
 }
 
-// ---------------------------------------------------------------- persistent balanced implicit GEMM
+// ---------------------------------------------------------------- persistent, balanced, block-lockstep implicit GEMM
 template <int CS, int CD>
-__global__ __launch_bounds__(256) void k_conv_mfma_pb(const float* __restrict__ src, const float* __restrict__ wp,
-                                                      const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
-                                                      int64_t n, const int64_t* d_n, const float* __restrict__ scale,
-                                                      const float* __restrict__ shift, int relu,
-                                                      const int32_t* __restrict__ plan, int64_t tcap,
-                                                      float* __restrict__ dst, float* __restrict__ scratch) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv_mfma_pbl(const float* __restrict__ src, const float* __restrict__ wp,
+                                                       const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
+                                                       int64_t n, const int64_t* d_n, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int relu,
+                                                       const int32_t* __restrict__ plan, int64_t t4cap,
+                                                       float* __restrict__ dst, float* __restrict__ scratch) {
   constexpr int NT = CD / 16;
   constexpr int JG = CS / 16;
-  extern __shared__ char occupancy_pad[];   // sized by the launch so that exactly 3 workgroups fit a CU
+  constexpr int NF = NT * JG;               // 1 KiB weight fragments per offset
+  __shared__ f32x4 sB[2][NF * 64];
+  extern __shared__ char occupancy_pad[];   // tops the footprint up to kLdsPerBlock
   (void)occupancy_pad;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nw = plan[0];
-  if (w >= nw) return;
-  const int U = plan[1], T = plan[2];
+  const int blk = blockIdx.x;
+  const int nb = plan[0];
+  if (blk >= nb) return;                    // whole workgroup: no barrier has been reached yet
+  const int U = plan[1], T4 = plan[2];
   const int64_t nlive = spx_live_n(d_n, n);
   const int32_t* mask = plan + plan_off_mask();
-  const int32_t* pre = plan + plan_off_pre(tcap);
-  const int u0 = (int)((int64_t)w * U / nw), u1 = (int)((int64_t)(w + 1) * U / nw);
+  const int32_t* pre = plan + plan_off_pre(t4cap);
+  const int u0 = block_u0(blk, U, nb), u1 = block_u0(blk + 1, U, nb);
   const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+  const int s_first = plan[plan_off_wstart() + blk];
 
-  for (int t = plan[plan_off_wstart() + w]; t < T; ++t) {
-    const int p0 = pre[t];
-    if (p0 >= u1) break;
-    const uint32_t m = (uint32_t)mask[t];
-    const int cnt = __popc(m);
-    const int first = u0 > p0 ? u0 - p0 : 0;            // units [first, last) of this tile, in loop order
-    const int last = u1 - p0 < cnt ? u1 - p0 : cnt;
-    if (first >= last) continue;
-    const int64_t row_base = (int64_t)t * 16;
-    const int64_t row = row_base + r;
-
-    f32x4 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // units [first, last) of this tile as a bit set over the LOOP index k (weights W_k, table row trow(k))
-    uint32_t todo = 0;
-    {
-      int j = 0;
-      for (int k = 0; k < K; ++k) {
-        const int trow = flip ? K - 1 - k : k;
-        if (!((m >> trow) & 1u)) continue;
-        if (j >= first && j < last) todo |= 1u << k;
-        ++j;
+  // ---- the workgroup's super-units in order (all values wave-uniform and equal in the four waves)
+  struct Cur {
+    int S, k;            // super-tile, loop index of the offset (weights W_k, table row trow(k)); S < 0: past the end
+    uint32_t mself;      // offset mask of THIS wave's tile of S
+    int whole;           // S belongs to this workgroup alone
+  };
+  int it_S = s_first - 1;
+  uint32_t it_todo = 0, it_mself = 0;
+  int it_whole = 0;
+  auto next = [&]() -> Cur {
+    while (it_todo == 0) {
+      ++it_S;
+      if (it_S >= T4) return Cur{-1, 0, 0u, 0};
+      const int p0 = pre[it_S];
+      if (p0 >= u1) return Cur{-1, 0, 0u, 0};
+      const int work = pre[it_S + 1] - p0;
+      if (work == 0) continue;                                   // empty super-tile: written by the fix-up kernel
+      const int4 m4 = *reinterpret_cast<const int4*>(mask + 4 * (size_t)it_S);
+      const uint32_t many = (uint32_t)(m4.x | m4.y | m4.z | m4.w);
+      it_mself = (uint32_t)(wave == 0 ? m4.x : wave == 1 ? m4.y : wave == 2 ? m4.z : m4.w);
+      it_whole = (u0 <= p0 && p0 + work <= u1) ? 1 : 0;
+      int c = p0;
+      for (int k = 0; k < K; ++k) {                              // owned: super-units whose index lies in [u0, u1)
+        const int tr = flip ? K - 1 - k : k;
+        if (!((many >> tr) & 1u)) continue;
+        if (c >= u0 && c < u1) it_todo |= 1u << k;
+        ++c;
       }
     }
-    const int64_t row_c = row < nlive ? row : nlive - 1;     // clamped: the load is unconditional
-    auto load_id = [&](int k) -> int32_t {
-      const int kk = k >= 0 ? k : 0;
-      const int32_t v = pair[(int64_t)(flip ? K - 1 - kk : kk) * ld + row_c];
-      return (k >= 0 && row < nlive) ? v : -1;
-    };
-    // unconditional (index clamped; lanes without a neighbour are zeroed when the rows are USED): a predicated load
-    // is a branch, and behind a branch the compiler waits vmcnt(0), i.e. for the weight fragments as well
-    auto gather = [&](int32_t id, f32x4 (&a)[JG]) {
-      const float* p = src + (size_t)(id > 0 ? id : 0) * CS + 4 * q;
-#pragma unroll
-      for (int jg = 0; jg < JG; ++jg) a[jg] = *reinterpret_cast<const f32x4*>(p + 16 * jg);
-    };
-    auto pop = [&]() -> int {          // next unit in loop order, -1 when none
-      if (todo == 0) return -1;
-      const int k = __ffs((int)todo) - 1;
-      todo &= todo - 1;
-      return k;
-    };
-    // Per unit the wave would otherwise wait out five memory round trips in sequence (rule entry, then weights + rows
-    // for each of the four 16-channel groups; ~14,000 cycles per unit against 2,048 of MFMA, measured).  Here the rule
-    // entries run two units ahead, the gathered rows one unit ahead, and the 16 weight fragments of the unit are
-    // requested together, in front of a scheduling fence, so that only the first fragment's latency is exposed.
-    int k_cur = pop();
-    int k_nxt = pop();
-    int32_t id_cur = load_id(k_cur), id_nxt = load_id(k_nxt);
-    f32x4 a_cur[JG], a_nxt[JG];
-    gather(id_cur, a_cur);
-    while (k_cur >= 0) {
-      f32x4 b[JG][NT];
-#pragma unroll
-      for (int jg = 0; jg < JG; ++jg)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[jg][nt] = wp4[((size_t)(k_cur * NT + nt) * JG + jg) * 64 + lane];
-      const int k_nn = pop();
-      const int32_t id_nn = load_id(k_nn);
-      gather(id_nxt, a_nxt);
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      const float keep = id_cur >= 0 ? 1.f : 0.f;
-#pragma unroll
-      for (int jg = 0; jg < JG; ++jg)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float av = id_cur >= 0 ? a_cur[jg][e] : 0.f;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[jg][nt][e], acc[nt], 0, 0, 0);
-        }
-      (void)keep;
-#pragma unroll
-      for (int jg = 0; jg < JG; ++jg) a_cur[jg] = a_nxt[jg];
-      k_cur = k_nxt;
-      k_nxt = k_nn;
-      id_cur = id_nxt;
-      id_nxt = id_nn;
-    }
+    const int k = __ffs((int)it_todo) - 1;
+    it_todo &= it_todo - 1;
+    return Cur{it_S, k, it_mself, it_whole};
+  };
 
-    // write-out.  C layout: col = lane&15, row = 4*(lane>>4) + e
-    const bool whole = first == 0 && last == cnt;
-    if (whole) {
+  auto copy_w = [&](int k, int buf) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int col = 16 * nt + r;
-        const float sc = scale ? scale[col] : 1.0f;
-        const float sh = shift ? shift[col] : 0.0f;
+    for (int i = 0; i < (NF + 3) / 4; ++i) {
+      const int f = wave + i * 4;           // wave-uniform
+      if (f < NF)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wp4 + ((size_t)k * NF + f) * 64 + lane),
+            (__attribute__((address_space(3))) void*)(&sB[buf][f * 64]), 16, 0, 0);
+    }
+  };
+  auto load_id = [&](const Cur& c) -> int32_t {              // unconditional (row clamped); -1 where not applicable
+    const int S = c.S >= 0 ? c.S : 0;
+    const int64_t row = (int64_t)S * 64 + 16 * wave + r;
+    const int64_t rc = row < nlive ? row : nlive - 1;
+    const int32_t v = pair[(int64_t)(flip ? K - 1 - c.k : c.k) * ld + rc];
+    return (c.S >= 0 && row < nlive) ? v : -1;
+  };
+  auto gather = [&](int32_t id, f32x4 (&a)[JG]) {            // unconditional (index clamped); masked when used
+    const float* p = src + (size_t)(id > 0 ? id : 0) * CS + 4 * q;
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg) a[jg] = *reinterpret_cast<const f32x4*>(p + 16 * jg);
+  };
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Pipeline: while super-unit c0 is multiplied, the rows of c1 and the weight slice of c1 are in flight and the rule
+  // entries of c2 are read; the barrier at the top of each trip is the one point where they are waited for.
+  Cur c0 = next(), c1 = next(), c2 = next();
+  int32_t id0 = load_id(c0), id1 = load_id(c1);
+  if (c0.S >= 0) copy_w(c0.k, 0);
+  f32x4 a_cur[JG], a_nxt[JG];
+  gather(id0, a_cur);
+  int it = 0;
+  while (c0.S >= 0) {
+    __syncthreads();   // W(c0) landed for every wave, a_cur / id1 arrived; the other weight buffer is free again
+    const int32_t id2 = load_id(c2);
+    gather(id1, a_nxt);
+    if (c1.S >= 0) copy_w(c1.k, (it + 1) & 1);
+    // everything above is only ISSUED here; keep it above the MFMAs (the scheduler would otherwise sink the gathers
+    // next to their use in the next trip and serialise latency and arithmetic again)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int tr0 = flip ? K - 1 - c0.k : c0.k;
+    if ((c0.mself >> tr0) & 1u) {            // wave-uniform: this wave's tile has the offset
+      const f32x4* B = sB[it & 1];
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) {
+        f32x4 b[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = B[(nt * JG + jg) * 64 + lane];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int64_t orow = row_base + 4 * q + e;
-          if (orow < nlive) {
-            float v = acc[nt][e];
-            if (scale || shift) v = v * sc + sh;
-            if (relu) v = v > 0.f ? v : 0.f;
-            dst[orow * CD + col] = v;
+          const float av = id0 >= 0 ? a_cur[jg][e] : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt][e], acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    if (c1.S != c0.S) {
+      // last owned offset of super-tile c0.S: write this wave's 16 rows.  C layout: col = lane&15, row = 4*(lane>>4) + e
+      const int64_t row_base = (int64_t)c0.S * 64 + 16 * wave;
+      if (c0.whole) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int col = 16 * nt + r;
+          const float sc = scale ? scale[col] : 1.0f;
+          const float sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int64_t orow = row_base + 4 * q + e;
+            if (orow < nlive) {
+              float v = acc[nt][e];
+              if (scale || shift) v = v * sc + sh;
+              if (relu) v = v > 0.f ? v : 0.f;
+              dst[orow * CD + col] = v;
+            }
           }
         }
+      } else {
+        // partial sums of a super-tile shared with neighbouring workgroups: slot 0 if it is this workgroup's first
+        // super-tile, else slot 1
+        float* out = scratch + ((size_t)2 * blk + (c0.S == s_first ? 0 : 1)) * (64 * CD) + (size_t)(16 * wave) * CD;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out[(4 * q + e) * CD + 16 * nt + r] = acc[nt][e];
       }
-    } else {
-      // partial sum of a cut tile: slot 2t = head part (units from 0), slot 2t+1 = tail part (units up to cnt)
-      float* out = scratch + ((size_t)2 * t + (first == 0 ? 0 : 1)) * (16 * CD);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) out[(4 * q + e) * CD + 16 * nt + r] = acc[nt][e];
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg) a_cur[jg] = a_nxt[jg];
+    id0 = id1;
+    id1 = id2;
+    c0 = c1;
+    c1 = c2;
+    c2 = next();
+    ++it;
   }
 }
 
-// ---------------------------------------------------------------- cut tiles: head part + tail part, epilogue
+// ---------------------------------------------------------------- shared super-tiles: sum the partials in workgroup order
 template <int CD>
-__global__ __launch_bounds__(256) void k_conv_fixup(const int32_t* __restrict__ plan, int64_t tcap, int64_t n,
+__global__ __launch_bounds__(256) void k_conv_fixup(const int32_t* __restrict__ plan, int64_t t4cap, int64_t n,
                                                     const int64_t* d_n, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, int relu,
                                                     const float* __restrict__ scratch, float* __restrict__ dst) {
-  constexpr int V = 16 * CD / 4;                       // float4 pieces per tile
-  const int T = plan[2];
-  const int t = blockIdx.x;
-  if (t >= T) return;
-  const int32_t m = plan[plan_off_mask() + t];
-  const bool cut = plan[plan_off_split(tcap) + t] != 0;
-  if (!cut && m != 0) return;                          // written whole by the main kernel
+  constexpr int V = 64 * CD / 4;                       // float4 pieces per super-tile
+  const int nb = plan[0], U = plan[1], T4 = plan[2];
+  const int S = blockIdx.x;
+  if (S >= T4) return;
+  const int32_t* pre = plan + plan_off_pre(t4cap);
+  const int32_t* wstart = plan + plan_off_wstart();
+  const int p0 = pre[S], work = pre[S + 1] - p0;
+  int b_lo = 0, b_hi = -1;
+  if (work > 0) {
+    // workgroups whose range meets [p0, p0 + work): b_lo = last one starting at or before p0, b_hi = last one starting
+    // before p0 + work
+    int a = 0, b = nb - 1;
+    while (a < b) {
+      int mid = (a + b + 1) >> 1;
+      if (block_u0(mid, U, nb) <= p0) a = mid; else b = mid - 1;
+    }
+    b_lo = a;
+    a = b_lo, b = nb - 1;
+    while (a < b) {
+      int mid = (a + b + 1) >> 1;
+      if (block_u0(mid, U, nb) < p0 + work) a = mid; else b = mid - 1;
+    }
+    b_hi = a;
+    if (b_hi == b_lo) return;                          // one owner: written whole by the main kernel
+  }
   const int64_t nlive = spx_live_n(d_n, n);
-  const f32x4* h = reinterpret_cast<const f32x4*>(scratch + (size_t)2 * t * (16 * CD));
-  const f32x4* tl = h + V;
   for (int i = threadIdx.x; i < V; i += 256) {
     const int rr = (4 * i) / CD, c0 = (4 * i) % CD;
-    const int64_t orow = (int64_t)t * 16 + rr;
+    const int64_t orow = (int64_t)S * 64 + rr;
     if (orow >= nlive) continue;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (cut) {
-      const f32x4 a = h[i], b = tl[i];
-      v = a + b;
+    for (int b = b_lo; b <= b_hi; ++b) {
+      const int slot = wstart[b] == S ? 0 : 1;
+      v += reinterpret_cast<const f32x4*>(scratch + ((size_t)2 * b + slot) * (64 * CD))[i];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -299,24 +353,25 @@ __global__ __launch_bounds__(256) void k_conv_fixup(const int32_t* __restrict__ 
   }
 }
 
-static inline int64_t tiles_cap(int64_t n) { return (n + 15) / 16 + 1; }
+static inline int64_t tiles4_cap(int64_t n) { return (n + 63) / 64 + 1; }
 
 template <int CS, int CD>
 static void launch_pb(const float* src, const float* wp, const int32_t* pair, int64_t ld, int K, int flip, int64_t n,
                       const int64_t* d_n, const float* scale, const float* shift, int relu, const int32_t* plan,
                       float* dst, float* scratch, hipStream_t s) {
-  const int64_t tcap = tiles_cap(n);
-  // 48 KiB of dynamic LDS per workgroup: three workgroups (12 waves, 3 per SIMD) fit a CU's 160 KiB, a fourth does not
-  hipLaunchKernelGGL((k_conv_mfma_pb<CS, CD>), dim3(kWaves / 4), dim3(256), 48 * 1024, s, src, wp, pair, ld, K, flip, n, d_n,
-                     scale, shift, relu, plan, tcap, dst, scratch);
-  hipLaunchKernelGGL((k_conv_fixup<CD>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, plan, tcap, n, d_n, scale, shift,
+  const int64_t t4cap = tiles4_cap(n);
+  constexpr int kStatic = 2 * (CS / 16) * (CD / 16) * 1024;      // the two weight buffers
+  const int pad = kLdsPerBlock > kStatic ? kLdsPerBlock - kStatic : 0;
+  hipLaunchKernelGGL((k_conv_mfma_pbl<CS, CD>), dim3(kBlocks), dim3(256), pad, s, src, wp, pair, ld, K, flip, n, d_n, scale,
+                     shift, relu, plan, t4cap, dst, scratch);
+  hipLaunchKernelGGL((k_conv_fixup<CD>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, plan, t4cap, n, d_n, scale, shift,
                      relu, scratch, dst);
 }
 
 }  // namespace
 
 extern "C" size_t spx_conv_plan_bytes(int64_t n_dst) {
-  return spx_align((size_t)plan_ints(tiles_cap(n_dst < 0 ? 0 : n_dst)) * sizeof(int32_t));
+  return spx_align((size_t)plan_ints(tiles4_cap(n_dst < 0 ? 0 : n_dst)) * sizeof(int32_t));
 }
 
 extern "C" int spx_conv_plan(const int32_t* pair, int64_t pair_ld, int kvol, int64_t n_dst, const int64_t* d_n_dst,
@@ -324,17 +379,17 @@ extern "C" int spx_conv_plan(const int32_t* pair, int64_t pair_ld, int kvol, int
   if (!pair || !plan || kvol <= 0 || kvol > SPX_MAX_KVOL || n_dst <= 0 || pair_ld < n_dst) return SPX_ERR_INVALID_ARG;
   if (n_dst >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
   hipStream_t s = spx_s(stream);
-  const int64_t tcap = tiles_cap(n_dst);
-  hipLaunchKernelGGL(k_plan_mask, dim3((unsigned)((tcap + 15) / 16)), dim3(256), 0, s, pair, pair_ld, kvol, n_dst, d_n_dst,
-                     tcap, plan);
-  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, kvol, n_dst, d_n_dst, tcap, plan);
+  const int64_t t4cap = tiles4_cap(n_dst);
+  hipLaunchKernelGGL(k_plan_mask, dim3((unsigned)((4 * t4cap + 15) / 16)), dim3(256), 0, s, pair, pair_ld, kvol, n_dst,
+                     d_n_dst, t4cap, plan);
+  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, n_dst, d_n_dst, t4cap, plan);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }
 
 extern "C" size_t spx_conv_gemm_balanced_ws_bytes(int c_dst, int64_t n_dst) {
   if (c_dst <= 0 || n_dst <= 0) return 0;
-  return spx_align((size_t)2 * tiles_cap(n_dst) * 16 * c_dst * sizeof(float));
+  return spx_align((size_t)2 * kBlocks * 64 * c_dst * sizeof(float));
 }
 
 #define SPX_PB_CASE(A, B)                                                                                            \

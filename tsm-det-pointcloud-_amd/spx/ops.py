@@ -204,7 +204,7 @@ def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=N
     return dst
 
 
-_BALANCED_SHAPES = {(32, 64), (64, 32), (64, 64)}   # 32x32 measured slower (weight-bandwidth bound either way)
+_BALANCED_SHAPES = {(64, 64)}   # measured: 32x32 slower, 32x64 / 64x32 even (plan cost included)
 # below this many destination rows the plan / fix-up launches cost more than the balanced schedule saves
 _BALANCED_MIN_ROWS = int(os.environ.get("SPX_CONV_BALANCED_MIN_ROWS", "24000"))
 _BALANCED = os.environ.get("SPX_CONV_BALANCED", "1") != "0"
