@@ -16,6 +16,7 @@ for p in (ROOT, os.path.join(ROOT, "tsm-det-pointcloud-_amd")):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layer", default="conv3.1.0")
+    ap.add_argument("--balanced", action="store_true", help="stamp the persistent balanced kernel (conv_balanced.hip)")
     ap.add_argument("--defs", default="", help="extra -D flags for conv_gemm.hip, comma separated (diag ablations)")
     args = ap.parse_args()
     csrc = os.path.join(ROOT, "tsm-det-pointcloud-_amd", "csrc")
@@ -24,7 +25,7 @@ def main():
     objs = []
     for f in [f for f in os.listdir(csrc) if f.endswith(".hip")]:
         o = os.path.join(out, f[:-4] + ".o")
-        flags = (["-DSPX_CV_DIAG"] + ["-D" + x for x in args.defs.split(",") if x]) if f == "conv_gemm.hip" else []
+        flags = (["-DSPX_CV_DIAG"] + ["-D" + x for x in args.defs.split(",") if x]) if f in ("conv_gemm.hip", "conv_balanced.hip") else []
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc",
                                *flags, "-c", os.path.join(csrc, f), "-o", o])
         objs.append(o)
@@ -63,6 +64,8 @@ def main():
     x = torch.randn(rb.n_in, cin, generator=g).to(dev)
     w = (torch.randn(cout, *ks, cin, generator=g) / np.sqrt(rb.kvol * cin)).to(dev)
     wp = ops.pack_weight(w, 0)
+    if args.balanced:
+        return diag_balanced(lib, ops, x, wp, cout, cin, rb, dev)
     nwaves = (rb.n_out + 15) // 16 + 8
     diag = torch.zeros(nwaves * 4, dtype=torch.int64, device=dev)
     lib.spx_diag_set_conv.restype = ctypes.c_int
@@ -108,6 +111,39 @@ def main():
     # resident waves over time
     ts = np.linspace(0, span_us, 11)
     print("resident waves at t:", " ".join("%.0f:%d" % (t, int(((st <= t) & (en > t)).sum())) for t in ts))
+
+
+def diag_balanced(lib, ops, x, wp, cout, cin, rb, dev):
+    import numpy as np
+    import torch
+    plan = ops.conv_plan(rb.pair, rb.ld, rb.kvol, rb.n_out)
+    diag = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+    lib.spx_diag_set_balanced.restype = ctypes.c_int
+    lib.spx_diag_set_balanced.argtypes = [ctypes.c_void_p]
+    for _ in range(20):
+        ops.conv_gemm_balanced(x, wp, cout, rb.kvol, rb.pair, rb.ld, rb.n_out, plan)
+    torch.cuda.synchronize()
+    assert lib.spx_diag_set_balanced(ctypes.c_void_p(diag.data_ptr())) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.conv_gemm_balanced(x, wp, cout, rb.kvol, rb.pair, rb.ld, rb.n_out, plan)
+    e1.record()
+    torch.cuda.synchronize()
+    hdr = plan[:4].cpu().numpy()
+    d = diag.cpu().numpy().reshape(-1, 8).astype(np.float64)
+    d = d[d[:, 0] > 0]
+    life, units, act, bar, mma, t0, t1 = [d[:, i] for i in range(7)]
+    clk = np.median(life / np.maximum(t1 - t0, 1)) * 100e6
+    floor = 32 * (cin // 4) * (cout // 16)
+    print("plan: workgroups %d  super-units %d  super-tiles %d ; waves stamped %d ; event %.1f us ; clock %.2f GHz" % (
+        hdr[0], hdr[1], hdr[2], d.shape[0], e0.elapsed_time(e1) * 1e3, clk / 1e9))
+    span = (t1.max() - t0.min()) / 100.0
+    print("main kernel span %.1f us ; wave lifetime us mean %.1f p10 %.1f p90 %.1f max %.1f" % (
+        span, (life / clk * 1e6).mean(), *np.percentile(life / clk * 1e6, [10, 90, 100])))
+    print("per wave: super-units %.1f, active in %.1f (%.0f %%) ; cycles per super-unit %.0f = barrier %.0f + mfma phase %.0f + rest %.0f ; MFMA floor per active unit %d" % (
+        units.mean(), act.mean(), 100 * act.sum() / units.sum(), life.sum() / units.sum(), bar.sum() / units.sum(),
+        mma.sum() / units.sum(), (life - bar - mma).sum() / units.sum(), floor))
+    print("MFMA floor of the launch %.1f us (active units x %d cycles / 1024 SIMDs)" % (act.sum() * floor / 1024 / clk * 1e6, floor))
 
 
 if __name__ == "__main__":

@@ -25,11 +25,22 @@
 
 #include "spx_common.h"
 
+#ifdef SPX_CV_DIAG
+// diagnostic build only (never shipped): per-wave cycle stamps, see tools/conv_diag.py --balanced
+__device__ unsigned long long* g_cb_diag = nullptr;
+extern "C" int spx_diag_set_balanced(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cb_diag), &p, sizeof(p)); }
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBlocks = 1024;       // persistent workgroups: 4 per CU (256 CUs), 4 waves each = 4 waves per SIMD
+#ifndef SPX_CB_WPB
+#define SPX_CB_WPB 4
+#endif
+constexpr int kWpb = SPX_CB_WPB;     // waves per workgroup = 16-row tiles per super-tile (4: 64 rows, 16: 256 rows)
+constexpr int kRows = 16 * kWpb;    // destination rows per super-tile
+constexpr int kBlocks = 4096 / kWpb;   // persistent workgroups: 4 waves per SIMD in total (256 CUs x 4 SIMDs)
 constexpr int kLdsPerBlock = 36 * 1024;   // LDS footprint forced per workgroup: four fit a CU's 160 KiB, a fifth not
 constexpr int kPreLds = 12 * 1024;  // prefix entries staged in LDS by the plan kernel (786k rows)
 constexpr int kHdr = 4;             // plan header: [0] active workgroups nb, [1] super-units U, [2] super-tiles T4, [3] -
@@ -37,7 +48,7 @@ constexpr int kHdr = 4;             // plan header: [0] active workgroups nb, [1
 // plan layout (int32): hdr[kHdr] | wstart[kBlocks + 1, padded] | mask[4 * T4cap] | pre4[T4cap + 1]
 __host__ __device__ inline int64_t plan_off_wstart() { return kHdr; }
 __host__ __device__ inline int64_t plan_off_mask() { return kHdr + (kBlocks + 1 + 3) / 4 * 4; }   // 16-byte aligned
-__host__ __device__ inline int64_t plan_off_pre(int64_t t4cap) { return plan_off_mask() + 4 * t4cap; }
+__host__ __device__ inline int64_t plan_off_pre(int64_t t4cap) { return plan_off_mask() + kWpb * t4cap; }
 __host__ __device__ inline int64_t plan_ints(int64_t t4cap) { return plan_off_pre(t4cap) + t4cap + 1; }
 
 // first super-unit of workgroup b when U super-units are dealt to nb workgroups
@@ -64,7 +75,7 @@ __global__ __launch_bounds__(256) void k_plan_mask(const int32_t* __restrict__ p
       if ((b >> (16 * sub)) & 0xFFFFull) m |= 1u << (k0 + u);
     }
   }
-  if (r == 0 && tile < 4 * t4cap) plan[plan_off_mask() + tile] = tile < T ? (int32_t)m : 0;
+  if (r == 0 && tile < kWpb * t4cap) plan[plan_off_mask() + tile] = tile < T ? (int32_t)m : 0;
 }
 
 // ---------------------------------------------------------------- plan, pass 2 (one block): prefix over super-tiles, cuts
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t n, const int64_t* d_
   __shared__ int s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t nlive = spx_live_n(d_n, n);
-  const int T4 = (int)((nlive + 63) / 64);
+  const int T4 = (int)((nlive + kRows - 1) / kRows);
   const int32_t* mask = plan + plan_off_mask();
   int32_t* pre = plan + plan_off_pre(t4cap);
   int32_t* wstart = plan + plan_off_wstart();
@@ -83,8 +94,13 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t n, const int64_t* d_
     const int S = base + tid;
     int v = 0;
     if (S < T4) {
-      const int4 m = *reinterpret_cast<const int4*>(mask + 4 * (size_t)S);
-      v = __popc((unsigned)(m.x | m.y | m.z | m.w));     // super-units: offsets present in any of the four tiles
+      int many = 0;
+#pragma unroll
+      for (int i = 0; i < kWpb; i += 4) {
+        const int4 m = *reinterpret_cast<const int4*>(mask + (size_t)kWpb * S + i);
+        many |= m.x | m.y | m.z | m.w;
+      }
+      v = __popc((unsigned)many);                        // super-units: offsets present in any tile of the super-tile
     }
     int incl = v;
 #pragma unroll
@@ -139,7 +155,7 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t n, const int64_t* d_
 
 // ---------------------------------------------------------------- persistent, balanced, block-lockstep implicit GEMM
 template <int CS, int CD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv_mfma_pbl(const float* __restrict__ src, const float* __restrict__ wp,
+__global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv_mfma_pbl(const float* __restrict__ src, const float* __restrict__ wp,
                                                        const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
                                                        int64_t n, const int64_t* d_n, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu,
@@ -181,9 +197,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       if (p0 >= u1) return Cur{-1, 0, 0u, 0};
       const int work = pre[it_S + 1] - p0;
       if (work == 0) continue;                                   // empty super-tile: written by the fix-up kernel
-      const int4 m4 = *reinterpret_cast<const int4*>(mask + 4 * (size_t)it_S);
-      const uint32_t many = (uint32_t)(m4.x | m4.y | m4.z | m4.w);
-      it_mself = (uint32_t)(wave == 0 ? m4.x : wave == 1 ? m4.y : wave == 2 ? m4.z : m4.w);
+      uint32_t many = 0;
+#pragma unroll
+      for (int i = 0; i < kWpb; i += 4) {
+        const int4 m4 = *reinterpret_cast<const int4*>(mask + (size_t)kWpb * it_S + i);
+        many |= (uint32_t)(m4.x | m4.y | m4.z | m4.w);
+      }
+      it_mself = (uint32_t)mask[(size_t)kWpb * it_S + wave];
       it_whole = (u0 <= p0 && p0 + work <= u1) ? 1 : 0;
       int c = p0;
       for (int k = 0; k < K; ++k) {                              // owned: super-units whose index lies in [u0, u1)
@@ -200,8 +220,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   auto copy_w = [&](int k, int buf) {
 #pragma unroll
-    for (int i = 0; i < (NF + 3) / 4; ++i) {
-      const int f = wave + i * 4;           // wave-uniform
+    for (int i = 0; i < (NF + kWpb - 1) / kWpb; ++i) {
+      const int f = wave + i * kWpb;        // wave-uniform
       if (f < NF)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(wp4 + ((size_t)k * NF + f) * 64 + lane),
@@ -210,7 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   };
   auto load_id = [&](const Cur& c) -> int32_t {              // unconditional (row clamped); -1 where not applicable
     const int S = c.S >= 0 ? c.S : 0;
-    const int64_t row = (int64_t)S * 64 + 16 * wave + r;
+    const int64_t row = (int64_t)S * kRows + 16 * wave + r;
     const int64_t rc = row < nlive ? row : nlive - 1;
     const int32_t v = pair[(int64_t)(flip ? K - 1 - c.k : c.k) * ld + rc];
     return (c.S >= 0 && row < nlive) ? v : -1;
@@ -227,6 +247,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   // Pipeline: while super-unit c0 is multiplied, the rows of c1 and the weight slice of c1 are in flight and the rule
   // entries of c2 are read; the barrier at the top of each trip is the one point where they are waited for.
+#ifdef SPX_CV_DIAG
+  const unsigned long long d_t0 = __builtin_amdgcn_s_memtime(), d_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long d_bar = 0, d_mma = 0, d_units = 0, d_act = 0;
+#endif
   Cur c0 = next(), c1 = next(), c2 = next();
   int32_t id0 = load_id(c0), id1 = load_id(c1);
   if (c0.S >= 0) copy_w(c0.k, 0);
@@ -234,7 +258,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   gather(id0, a_cur);
   int it = 0;
   while (c0.S >= 0) {
+#ifdef SPX_CV_DIAG
+    const unsigned long long d_a = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();   // W(c0) landed for every wave, a_cur / id1 arrived; the other weight buffer is free again
+#ifdef SPX_CV_DIAG
+    d_bar += __builtin_amdgcn_s_memtime() - d_a;
+    d_units += 1;
+#endif
     const int32_t id2 = load_id(c2);
     gather(id1, a_nxt);
     if (c1.S >= 0) copy_w(c1.k, (it + 1) & 1);
@@ -243,6 +274,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     const int tr0 = flip ? K - 1 - c0.k : c0.k;
+#ifdef SPX_CV_DIAG
+    const unsigned long long d_c = __builtin_amdgcn_s_memtime();
+    if ((c0.mself >> tr0) & 1u) d_act += 1;
+#endif
     if ((c0.mself >> tr0) & 1u) {            // wave-uniform: this wave's tile has the offset
       const f32x4* B = sB[it & 1];
 #pragma unroll
@@ -258,9 +293,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
       }
     }
+#ifdef SPX_CV_DIAG
+    d_mma += __builtin_amdgcn_s_memtime() - d_c;
+#endif
     if (c1.S != c0.S) {
       // last owned offset of super-tile c0.S: write this wave's 16 rows.  C layout: col = lane&15, row = 4*(lane>>4) + e
-      const int64_t row_base = (int64_t)c0.S * 64 + 16 * wave;
+      const int64_t row_base = (int64_t)c0.S * kRows + 16 * wave;
       if (c0.whole) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -281,7 +319,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       } else {
         // partial sums of a super-tile shared with neighbouring workgroups: slot 0 if it is this workgroup's first
         // super-tile, else slot 1
-        float* out = scratch + ((size_t)2 * blk + (c0.S == s_first ? 0 : 1)) * (64 * CD) + (size_t)(16 * wave) * CD;
+        float* out = scratch + ((size_t)2 * blk + (c0.S == s_first ? 0 : 1)) * (kRows * CD) + (size_t)(16 * wave) * CD;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -299,6 +337,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     c2 = next();
     ++it;
   }
+#ifdef SPX_CV_DIAG
+  if (g_cb_diag && lane == 0) {
+    unsigned long long* o = g_cb_diag + ((size_t)blk * kWpb + wave) * 8;
+    o[0] = __builtin_amdgcn_s_memtime() - d_t0;   // wave lifetime, core cycles
+    o[1] = d_units;                               // super-units walked
+    o[2] = d_act;                                 // super-units in which this wave multiplied
+    o[3] = d_bar;                                 // cycles inside __syncthreads (incl. its vmcnt(0) drain)
+    o[4] = d_mma;                                 // cycles in the LDS-read + MFMA phase
+    o[5] = d_r0;                                  // start, 100 MHz ticks
+    o[6] = __builtin_amdgcn_s_memrealtime();      // end
+    o[7] = 0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- shared super-tiles: sum the partials in workgroup order
@@ -307,7 +358,7 @@ __global__ __launch_bounds__(256) void k_conv_fixup(const int32_t* __restrict__ 
                                                     const int64_t* d_n, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, int relu,
                                                     const float* __restrict__ scratch, float* __restrict__ dst) {
-  constexpr int V = 64 * CD / 4;                       // float4 pieces per super-tile
+  constexpr int V = kRows * CD / 4;                    // float4 pieces per super-tile
   const int nb = plan[0], U = plan[1], T4 = plan[2];
   const int S = blockIdx.x;
   if (S >= T4) return;
@@ -335,12 +386,12 @@ __global__ __launch_bounds__(256) void k_conv_fixup(const int32_t* __restrict__ 
   const int64_t nlive = spx_live_n(d_n, n);
   for (int i = threadIdx.x; i < V; i += 256) {
     const int rr = (4 * i) / CD, c0 = (4 * i) % CD;
-    const int64_t orow = (int64_t)S * 64 + rr;
+    const int64_t orow = (int64_t)S * kRows + rr;
     if (orow >= nlive) continue;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int b = b_lo; b <= b_hi; ++b) {
       const int slot = wstart[b] == S ? 0 : 1;
-      v += reinterpret_cast<const f32x4*>(scratch + ((size_t)2 * b + slot) * (64 * CD))[i];
+      v += reinterpret_cast<const f32x4*>(scratch + ((size_t)2 * b + slot) * (kRows * CD))[i];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -353,7 +404,7 @@ __global__ __launch_bounds__(256) void k_conv_fixup(const int32_t* __restrict__ 
   }
 }
 
-static inline int64_t tiles4_cap(int64_t n) { return (n + 63) / 64 + 1; }
+static inline int64_t tiles4_cap(int64_t n) { return (n + kRows - 1) / kRows + 1; }
 
 template <int CS, int CD>
 static void launch_pb(const float* src, const float* wp, const int32_t* pair, int64_t ld, int K, int flip, int64_t n,
@@ -361,10 +412,11 @@ static void launch_pb(const float* src, const float* wp, const int32_t* pair, in
                       float* dst, float* scratch, hipStream_t s) {
   const int64_t t4cap = tiles4_cap(n);
   constexpr int kStatic = 2 * (CS / 16) * (CD / 16) * 1024;      // the two weight buffers
-  const int pad = kLdsPerBlock > kStatic ? kLdsPerBlock - kStatic : 0;
-  hipLaunchKernelGGL((k_conv_mfma_pbl<CS, CD>), dim3(kBlocks), dim3(256), pad, s, src, wp, pair, ld, K, flip, n, d_n, scale,
+  // (a 16-wave workgroup fills a CU's wave slots at this register count by itself: no padding needed)
+  const int pad = (kWpb == 4 && kLdsPerBlock > kStatic) ? kLdsPerBlock - kStatic : 0;
+  hipLaunchKernelGGL((k_conv_mfma_pbl<CS, CD>), dim3(kBlocks), dim3(64 * kWpb), pad, s, src, wp, pair, ld, K, flip, n, d_n, scale,
                      shift, relu, plan, t4cap, dst, scratch);
-  hipLaunchKernelGGL((k_conv_fixup<CD>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, plan, t4cap, n, d_n, scale, shift,
+  hipLaunchKernelGGL((k_conv_fixup<CD>), dim3((unsigned)((n + kRows - 1) / kRows)), dim3(256), 0, s, plan, t4cap, n, d_n, scale, shift,
                      relu, scratch, dst);
 }
 
@@ -380,7 +432,7 @@ extern "C" int spx_conv_plan(const int32_t* pair, int64_t pair_ld, int kvol, int
   if (n_dst >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
   hipStream_t s = spx_s(stream);
   const int64_t t4cap = tiles4_cap(n_dst);
-  hipLaunchKernelGGL(k_plan_mask, dim3((unsigned)((4 * t4cap + 15) / 16)), dim3(256), 0, s, pair, pair_ld, kvol, n_dst,
+  hipLaunchKernelGGL(k_plan_mask, dim3((unsigned)((kWpb * t4cap + 15) / 16)), dim3(256), 0, s, pair, pair_ld, kvol, n_dst,
                      d_n_dst, t4cap, plan);
   hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, n_dst, d_n_dst, t4cap, plan);
   SPX_CHECK_LAUNCH();
@@ -389,7 +441,7 @@ extern "C" int spx_conv_plan(const int32_t* pair, int64_t pair_ld, int kvol, int
 
 extern "C" size_t spx_conv_gemm_balanced_ws_bytes(int c_dst, int64_t n_dst) {
   if (c_dst <= 0 || n_dst <= 0) return 0;
-  return spx_align((size_t)2 * kBlocks * 64 * c_dst * sizeof(float));
+  return spx_align((size_t)2 * kBlocks * kRows * c_dst * sizeof(float));
 }
 
 #define SPX_PB_CASE(A, B)                                                                                            \
