@@ -144,6 +144,28 @@ def diag_balanced(lib, ops, x, wp, cout, cin, rb, dev):
         units.mean(), act.mean(), 100 * act.sum() / units.sum(), life.sum() / units.sum(), bar.sum() / units.sum(),
         mma.sum() / units.sum(), (life - bar - mma).sum() / units.sum(), floor))
     print("MFMA floor of the launch %.1f us (active units x %d cycles / 1024 SIMDs)" % (act.sum() * floor / 1024 / clk * 1e6, floor))
+    raw = diag.cpu().numpy().reshape(-1, 8)
+    raw = raw[raw[:, 0] > 0]
+    hw = raw[:, 7] & 0xFFFFFFFF
+    xcc = (raw[:, 7] >> 32) & 0xF
+    simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+    cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    simd_key = cu_key * 4 + simd
+    import collections
+    per_simd = collections.Counter(simd_key.tolist())
+    per_cu = collections.Counter(cu_key.tolist())
+    print("placement: %d CUs used, waves per CU %s ; %d SIMDs used, waves per SIMD %s" % (
+        len(per_cu), dict(collections.Counter(per_cu.values())), len(per_simd), dict(collections.Counter(per_simd.values()))))
+    lt = life / clk * 1e6
+    print("   lifetime by XCC:", " ".join("%d:%.0f" % (x, lt[xcc == x].mean()) for x in sorted(set(xcc.tolist()))))
+    print("   cycles per super-unit by XCC:", " ".join("%d:%.0f" % (x, life[xcc == x].sum() / units[xcc == x].sum()) for x in sorted(set(xcc.tolist()))))
+    blk_id = np.arange(raw.shape[0]) // 4
+    q4 = np.array_split(np.argsort(blk_id, kind="stable"), 8)
+    print("   lifetime by workgroup-index octile:", " ".join("%.0f" % lt[i].mean() for i in q4))
+    print("   active share by octile:", " ".join("%.2f" % (act[i].sum() / units[i].sum()) for i in q4))
+    for nws in sorted(set(per_simd.values())):
+        sel = np.array([per_simd[k] == nws for k in simd_key.tolist()])
+        print("   waves on a SIMD holding %d waves: %5d  lifetime mean %.1f us" % (nws, sel.sum(), lt[sel].mean()))
 
 
 if __name__ == "__main__":
