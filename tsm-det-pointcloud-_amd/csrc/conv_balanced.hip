@@ -347,7 +347,10 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
     o[4] = d_mma;                                 // cycles in the LDS-read + MFMA phase
     o[5] = d_r0;                                  // start, 100 MHz ticks
     o[6] = __builtin_amdgcn_s_memrealtime();      // end
-    o[7] = 0;
+    unsigned hw = 0, xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    o[7] = (unsigned long long)hw | ((unsigned long long)xcc << 32);   // where the wave ran (SIMD / CU / SE / XCC)
   }
 #endif
 }
