@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * WPB) void k_conv_mfma(const float* __restrict_
 // registers.  One barrier per offset.  A wave whose 16 rows have no neighbour at k skips its MFMAs but not the barrier.
 // Same summation order per output element as k_conv_mfma (offsets ascending, channels in packed order): identical bits.
 template <int CS, int CD, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_conv_mfma_ls(const float* __restrict__ src, const float* __restrict__ wp,
+__global__ __launch_bounds__(64 * WPB) void k_conv_mfma_ls(const float* __restrict__ src, const float* __restrict__ wp,
                                                            const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
                                                            int64_t n, const int64_t* d_n, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
