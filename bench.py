@@ -284,19 +284,24 @@ def roofline_of(fam):
         ach, peak, unit, bound = d["flops"] / t / 1e12, MFMA_F32_PEAK / 1e12, "TFLOP/s", "mfma"
     else:
         ach, peak, unit, bound = d["bytes"] / t / 1e9, HBM_PEAK / 1e9, "GB/s", "hbm"
-    rocprof_name = "?"
+    rocprof_name, extra_name = "?", None
     if name.startswith("conv_gemm[mfma ") and name.endswith(" balanced]"):
         cs, cd = name[len("conv_gemm[mfma "):-len(" balanced]")].split("x")
-        rocprof_name = "k_conv_mfma_pbl<%s, %s>" % (cs, cd)      # event time also covers its k_conv_fixup (~6 us)
+        rocprof_name = "k_conv_mfma_pbl<%s, %s>" % (cs, cd)      # one API call = this kernel + its k_conv_fixup<cd>
+        extra_name = "k_conv_fixup<%s>" % cd
     elif name.startswith("conv_gemm[mfma "):
         cs, cd = name[len("conv_gemm[mfma "):-1].split("x")
         rocprof_name = "k_conv_mfma<%s, %s," % (cs, cd)
     elif name == "conv_wgrad":
         rocprof_name = "k_wgrad_mfma"
-    return {"kernel": name, "rocprof_kernel": rocprof_name + (" ...>" if rocprof_name.endswith(",") else ""),
+    traffic = pmc_traffic(rocprof_name)
+    if traffic is not None and extra_name is not None:
+        traffic += pmc_traffic(extra_name) or 0.0
+    return {"kernel": name, "rocprof_kernel": rocprof_name + (" ...>" if rocprof_name.endswith(",") else "") +
+                                                (" + " + extra_name if extra_name else ""),
             "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
             "frac": round(ach / peak, 4),
-            "traffic": pmc_traffic(rocprof_name),
+            "traffic": traffic,
             "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches_per_step"],
             "algorithmic_flops_per_launch": d["flops"] / d["launches"],
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"]}
