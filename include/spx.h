@@ -256,7 +256,8 @@ size_t spx_bn_relu_ws_bytes(int c);
 int spx_bn_relu_fwd(const float *x, int64_t n, const int64_t *d_n, int c, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, float momentum, float eps, int relu, float *y,
                     float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, spx_stream_t stream);
-int spx_bn_relu_bwd(const float *x, const float *y, const float *dy, int64_t n, int c, const float *gamma,
+/* backward: the ReLU mask is recomputed from x (same instruction sequence as the forward), y is not needed */
+int spx_bn_relu_bwd(const float *x, const float *dy, int64_t n, int c, const float *gamma, const float *beta,
                     const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma, float *dbeta,
                     void *ws, size_t ws_bytes, spx_stream_t stream);
 

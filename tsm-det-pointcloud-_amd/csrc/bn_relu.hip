@@ -6,8 +6,8 @@
 // The stock kernels cost three launches forward and three backward per layer and stream [N,C] at ~0.4 TB/s; here
 //   forward : k_bn_stats (one coalesced float4 pass, per-block partial sums) -> k_bn_finalize (fp64 combine, running
 //             statistics update) -> k_bn_apply (normalise + affine + ReLU, one read one write)
-//   backward: k_bn_bwd_reduce (sum dz, sum dz*xhat with the ReLU mask applied on the fly) -> k_bn_bwd_finalize ->
-//             k_bn_bwd_apply (dx)
+//   backward: k_bn_reduce<true> (sum dz, sum dz*xhat; the ReLU mask is RECOMPUTED from x, y is not read back) ->
+//             k_bn_bwd_finalize -> k_bn_bwd_apply (dx)
 // Partials are combined in a fixed order (no float atomics): bitwise reproducible.
 #include "spx_common.h"
 
@@ -16,12 +16,26 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxBlocks = 1024;
 
+// z = (x - mean) * invstd * gamma + beta, written so that forward and backward execute the SAME instruction sequence:
+// the backward pass recomputes the ReLU mask (z > 0) from x instead of reading y back (one [N, C] pass less in the
+// reduce and one less in the apply kernel), and the mask must agree with the forward bit for bit.
+__device__ __forceinline__ f32x4 bn_affine(f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) {
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float t = __fmul_rn(__fsub_rn(v[e], mu[e]), is[e]);
+    o[e] = __builtin_fmaf(t, ga[e], be[e]);
+  }
+  return o;
+}
+
 // grid-stride over float4 elements of x[N][C]; because 256*4 % C == 0 is NOT assumed, each thread recomputes its channel
 template <bool BWD>
-__global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ x, const float* __restrict__ y,
-                                                   const float* __restrict__ dy, const float* __restrict__ mean,
-                                                   const float* __restrict__ invstd, int64_t n, const int64_t* d_n, int C,
-                                                   int relu, float* __restrict__ partial /*[grid][2][C]*/) {
+__global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ dy,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                   int64_t n, const int64_t* d_n, int C, int relu,
+                                                   float* __restrict__ partial /*[grid][2][C]*/) {
   __shared__ float sm[256][8];   // per-thread partials (4 channels x {a, b})
   const int64_t nlive = spx_live_n(d_n, n);
   const int64_t total4 = nlive * C / 4;
@@ -32,9 +46,12 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ x, 
   const int c0 = (int)((start * 4) % C);
   f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f}, is = f32x4{1.f, 1.f, 1.f, 1.f};
+  f32x4 ga = f32x4{1.f, 1.f, 1.f, 1.f}, be = f32x4{0.f, 0.f, 0.f, 0.f};
   if (BWD) {
     mu = *reinterpret_cast<const f32x4*>(mean + c0);
     is = *reinterpret_cast<const f32x4*>(invstd + c0);
+    ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+    be = *reinterpret_cast<const f32x4*>(beta + c0);
   }
   for (int64_t i = start; i < total4; i += stride) {
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
@@ -44,7 +61,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ x, 
     } else {
       f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
       if (relu) {
-        f32x4 o = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 o = bn_affine(v, mu, is, ga, be);
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
       }
@@ -117,7 +134,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
     f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
     f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
-    f32x4 o = (v - mu) * is * ga + be;
+    f32x4 o = bn_affine(v, mu, is, ga, be);
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(64) void k_bn_bwd_finalize(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ beta,
                                                       const float* __restrict__ dy, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ dgamma, const float* __restrict__ dbeta,
@@ -153,13 +170,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     const int c0 = (int)((i * 4) % C);
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
     f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
+    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
     if (relu) {
-      f32x4 o = reinterpret_cast<const f32x4*>(y)[i];
+      const f32x4 o = bn_affine(v, mu, is, ga, *reinterpret_cast<const f32x4*>(beta + c0));
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
     }
-    f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
-    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
     f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c0), db = *reinterpret_cast<const f32x4*>(dbeta + c0);
     f32x4 xh = (v - mu) * is;
     reinterpret_cast<f32x4*>(dx)[i] = ga * is * (g - db * invN - xh * dg * invN);
@@ -188,7 +205,7 @@ extern "C" int spx_bn_relu_fwd(const float* x, int64_t n, const int64_t* d_n, in
   hipStream_t s = spx_s(stream);
   float* partial = reinterpret_cast<float*>(ws);
   int nb = bn_blocks(n, c);
-  hipLaunchKernelGGL((k_bn_reduce<false>), dim3(nb), dim3(256), 0, s, x, nullptr, nullptr, nullptr,
+  hipLaunchKernelGGL((k_bn_reduce<false>), dim3(nb), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr,
                      nullptr, n, d_n, c, relu, partial);
   hipLaunchKernelGGL(k_bn_finalize, dim3(c), dim3(64), 0, s, partial, nb, c, n, d_n, eps, momentum, save_mean,
                      save_invstd, running_mean, running_var);
@@ -198,21 +215,21 @@ extern "C" int spx_bn_relu_fwd(const float* x, int64_t n, const int64_t* d_n, in
   return SPX_OK;
 }
 
-extern "C" int spx_bn_relu_bwd(const float* x, const float* y, const float* dy, int64_t n, int c, const float* gamma,
+extern "C" int spx_bn_relu_bwd(const float* x, const float* dy, int64_t n, int c, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
                                float* dbeta, void* ws, size_t ws_bytes, spx_stream_t stream) {
-  if (!x || !y || !dy || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || n <= 0 || c <= 0)
+  if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || n <= 0 || c <= 0)
     return SPX_ERR_INVALID_ARG;
   if (c % 4 != 0 || 1024 % c != 0) return SPX_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < spx_bn_relu_ws_bytes(c)) return SPX_ERR_WORKSPACE;
   hipStream_t s = spx_s(stream);
   float* partial = reinterpret_cast<float*>(ws);
   int nb = bn_blocks(n, c);
-  hipLaunchKernelGGL((k_bn_reduce<true>), dim3(nb), dim3(256), 0, s, x, y, dy, save_mean, save_invstd,
-                     n, nullptr, c, relu, partial);
+  hipLaunchKernelGGL((k_bn_reduce<true>), dim3(nb), dim3(256), 0, s, x, gamma, beta, dy, save_mean, save_invstd, n,
+                     nullptr, c, relu, partial);
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(c), dim3(64), 0, s, partial, nb, c, dgamma, dbeta);
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(nb), dim3(256), 0, s, x, y, dy, save_mean, save_invstd, gamma, dgamma, dbeta, n,
-                     c, relu, dx);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(nb), dim3(256), 0, s, x, beta, dy, save_mean, save_invstd, gamma, dgamma, dbeta,
+                     n, c, relu, dx);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }

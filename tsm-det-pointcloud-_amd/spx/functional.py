@@ -120,15 +120,15 @@ class _BNReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
         y, mean, invstd = ops.bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu)
-        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.relu = relu
         ctx.mark_non_differentiable(running_mean, running_var) if running_mean is not None else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, mean, invstd = ctx.saved_tensors
-        dx, dgamma, dbeta = ops.bn_relu_bwd(x, y, dy, gamma, mean, invstd, ctx.relu)
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.bn_relu_bwd(x, dy, gamma, beta, mean, invstd, ctx.relu)
         return dx, dgamma, dbeta, None, None, None, None, None
 
 

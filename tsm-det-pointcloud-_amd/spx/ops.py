@@ -407,8 +407,9 @@ def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu):
     return y, mean, invstd
 
 
-def bn_relu_bwd(x, y, dy, gamma, mean, invstd, relu):
-    _need_gpu(x, y, dy)
+def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu):
+    """Backward of bn_relu_fwd; the ReLU mask is recomputed from x inside the kernels (y is not read)."""
+    _need_gpu(x, dy)
     lib = _lib.load()
     dy = dy.contiguous()
     n, c = x.shape
@@ -419,6 +420,7 @@ def bn_relu_bwd(x, y, dy, gamma, mean, invstd, relu):
         return dx, dgamma.zero_(), dbeta.zero_()
     wsb = lib.spx_bn_relu_ws_bytes(c)
     ws = workspace(x.device, wsb)
-    check(lib.spx_bn_relu_bwd(_ptr(x), _ptr(y), _ptr(dy), n, c, _ptr(gamma), _ptr(mean), _ptr(invstd), int(bool(relu)),
-                              _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream(x)), "spx_bn_relu_bwd")
+    check(lib.spx_bn_relu_bwd(_ptr(x), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd),
+                              int(bool(relu)), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream(x)),
+          "spx_bn_relu_bwd")
     return dx, dgamma, dbeta
