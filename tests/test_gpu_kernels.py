@@ -282,6 +282,28 @@ def test_conv_balanced_schedule_matches_tile_per_wave(orc):
         assert _rel_t(out, ref) < 2e-6 and float(out.min()) >= 0.0
 
 
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 200, 1000, 5000])
+def test_conv_balanced_small_and_ragged_sizes(n):
+    """The balanced schedule at sizes where most workgroups have nothing to do, rows do not fill the last 16-row tile /
+    64-row super-tile, and (n = 1) a single super-unit exists: same results as the one-tile-per-wave kernel."""
+    from spx import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(100 + n)
+    # n distinct voxels in a small grid -> a submanifold rulebook with a few neighbours per row
+    side = max(4, int(np.ceil((2.5 * n) ** (1.0 / 3.0))))
+    lin = torch.randperm(side ** 3, generator=g)[:n].sort()[0]
+    idx = torch.stack([torch.zeros_like(lin), lin // (side * side), (lin // side) % side, lin % side], 1).int().to(dev)
+    rb = ops.subm_rulebook(idx, 1, [side, side, side], (3, 3, 3))
+    w = (torch.randn(64, 3, 3, 3, 64, generator=g) / 40.0).to(dev)
+    wp = ops.pack_weight(w, 0)
+    x = torch.randn(n, 64, generator=g).to(dev)
+    plan = ops.conv_plan(rb.pair, rb.ld, 27, n)
+    for flip in (False, True):
+        ref = ops.conv_gemm(x, wp, 64, 27, rb.pair, rb.ld, n, flip_k=flip)
+        out = ops.conv_gemm_balanced(x, wp, 64, 27, rb.pair, rb.ld, n, plan, flip_k=flip)
+        assert _rel_t(out, ref) < 2e-6
+
+
 def _rel_t(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12))
 
