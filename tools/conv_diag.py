@@ -163,6 +163,22 @@ def diag_balanced(lib, ops, x, wp, cout, cin, rb, dev):
     q4 = np.array_split(np.argsort(blk_id, kind="stable"), 8)
     print("   lifetime by workgroup-index octile:", " ".join("%.0f" % lt[i].mean() for i in q4))
     print("   active share by octile:", " ".join("%.2f" % (act[i].sum() / units[i].sum()) for i in q4))
+    t_end = (t1 - t0.min()) / 100.0
+    t_beg = (t0 - t0.min()) / 100.0
+    simd_end = collections.defaultdict(float)
+    simd_beg = collections.defaultdict(lambda: 1e9)
+    simd_act = collections.defaultdict(float)
+    for kk, e_, b_, a_ in zip(simd_key.tolist(), t_end.tolist(), t_beg.tolist(), act.tolist()):
+        simd_end[kk] = max(simd_end[kk], e_)
+        simd_beg[kk] = min(simd_beg[kk], b_)
+        simd_act[kk] += a_
+    ends = np.array(list(simd_end.values()))
+    begs = np.array(list(simd_beg.values()))
+    acts = np.array([simd_act[k_] for k_ in simd_end])
+    print("   per SIMD: first wave starts at us p50 %.1f max %.1f ; last wave ends at us p10 %.1f p50 %.1f p90 %.1f max %.1f" % (
+        np.percentile(begs, 50), begs.max(), *np.percentile(ends, [10, 50, 90, 100])))
+    print("   per SIMD: active units min %.0f p50 %.0f max %.0f ; MFMA busy share until its own end: p10 %.2f p50 %.2f p90 %.2f" % (
+        acts.min(), np.median(acts), acts.max(), *np.percentile(acts * floor / clk * 1e6 / ends, [10, 50, 90])))
     for nws in sorted(set(per_simd.values())):
         sel = np.array([per_simd[k] == nws for k in simd_key.tolist()])
         print("   waves on a SIMD holding %d waves: %5d  lifetime mean %.1f us" % (nws, sel.sum(), lt[sel].mean()))
