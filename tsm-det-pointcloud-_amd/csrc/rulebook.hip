@@ -201,12 +201,25 @@ __global__ void k_scan_expand(const uint64_t* __restrict__ bits, int64_t nwords,
     // decode the word's first cell ONCE (64-bit divisions are ~100 instructions each on the GPU), then walk the set
     // bits with 32-bit carries: the 64 cells of a word are consecutive in x and wrap into y / z / batch
     int64_t key0 = (w0 + j) << 6;
-    int x0 = (int)(key0 % out_shape.v[2]);
-    int64_t t = key0 / out_shape.v[2];
-    int y0 = (int)(t % out_shape.v[1]);
-    t /= out_shape.v[1];
-    int z0 = (int)(t % out_shape.v[0]);
-    int b0 = (int)(t / out_shape.v[0]);
+    int x0, y0, z0, b0;
+    if ((nwords << 6) < (int64_t(1) << 31)) {        // grid-uniform: 32-bit divisions (~5x cheaper) when the keys fit
+      const uint32_t k32 = (uint32_t)key0;
+      const uint32_t sx = (uint32_t)out_shape.v[2], sy = (uint32_t)out_shape.v[1], sz = (uint32_t)out_shape.v[0];
+      uint32_t t = k32 / sx;
+      x0 = (int)(k32 - t * sx);
+      uint32_t t2 = t / sy;
+      y0 = (int)(t - t2 * sy);
+      uint32_t t3 = t2 / sz;
+      z0 = (int)(t2 - t3 * sz);
+      b0 = (int)t3;
+    } else {
+      x0 = (int)(key0 % out_shape.v[2]);
+      int64_t t = key0 / out_shape.v[2];
+      y0 = (int)(t % out_shape.v[1]);
+      t /= out_shape.v[1];
+      z0 = (int)(t % out_shape.v[0]);
+      b0 = (int)(t / out_shape.v[0]);
+    }
     while (m) {
       int b = __ffsll((unsigned long long)m) - 1;
       m &= m - 1;
