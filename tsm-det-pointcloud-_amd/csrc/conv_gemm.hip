@@ -167,6 +167,117 @@ __global__ __launch_bounds__(64 * WPB) void k_conv_mfma(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------- MFMA implicit GEMM, low-channel layers (latency form)
+// For c_src * c_dst <= 2048 a (tile, offset) unit is 4-32 MFMAs, and k_conv_mfma spends its time waiting: rule entry ->
+// (weights + rows -> MFMA) per 16-channel group, each step a full memory round trip (the compiler keeps `load, wait
+// vmcnt(0), multiply` per group, and the per-offset `continue` is a branch it cannot count waits across).  Here
+//   phase 1: the wave reads all K rule entries of its 16 rows up front (K independent loads, no branch), keeps them in
+//            LDS and derives the set of non-empty offsets by ballot;
+//   phase 2: it walks only the non-empty offsets; the rows of the NEXT offset are gathered (unconditionally, index
+//            clamped, masked when used) and the weight fragments of the current one requested before a scheduling fence,
+//            so a unit costs one partially hidden round trip instead of up to five.
+// Same summation order as k_conv_mfma (offsets ascending, channels in packed order): identical bits.
+template <int CS, int CD>
+__global__ __launch_bounds__(256) void k_conv_mfma_sm(const float* __restrict__ src, const float* __restrict__ wp,
+                                                      const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
+                                                      int64_t n, const int64_t* d_n, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int relu,
+                                                      float* __restrict__ dst) {
+  constexpr int NT = CD / 16;
+  constexpr int JG = CS / 16;
+  __shared__ int32_t s_id[4][SPX_MAX_KVOL][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t nlive = spx_live_n(d_n, n);
+  const int64_t row_base = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (row_base >= nlive) return;            // no barrier is used: waves are independent
+  const int64_t row = row_base + r;
+  const int64_t rowc = row < nlive ? row : nlive - 1;
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+
+  // phase 1: rule entries of this tile for every offset (loop index k <-> table row K-1-k when flipped)
+  uint32_t todo = 0;
+  for (int k0 = 0; k0 < K; k0 += 9) {
+    int32_t id[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int k = k0 + u < K ? k0 + u : K - 1;
+      id[u] = pair[(int64_t)(flip ? K - 1 - k : k) * ld + rowc];
+    }
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int32_t v = (k0 + u < K && row < nlive) ? id[u] : -1;
+      if (__ballot(v >= 0) != 0ull) todo |= 1u << (k0 + u);
+      if (q == 0 && k0 + u < K) s_id[wave][k0 + u][r] = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto gather = [&](int32_t id, f32x4 (&a)[JG]) {
+    const float* p = src + (size_t)(id > 0 ? id : 0) * CS + 4 * q;
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg) a[jg] = *reinterpret_cast<const f32x4*>(p + 16 * jg);
+  };
+  auto pop = [&]() -> int {
+    if (todo == 0) return -1;
+    const int k = __ffs((int)todo) - 1;
+    todo &= todo - 1;
+    return k;
+  };
+
+  // phase 2
+  int k_cur = pop(), k_nxt = pop();
+  int32_t id_cur = k_cur >= 0 ? s_id[wave][k_cur][r] : -1;
+  f32x4 a_cur[JG], a_nxt[JG];
+  gather(id_cur, a_cur);
+  while (k_cur >= 0) {
+    f32x4 b[JG][NT];
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[jg][nt] = wp4[((size_t)(k_cur * NT + nt) * JG + jg) * 64 + lane];
+    const int32_t id_nxt = s_id[wave][k_nxt >= 0 ? k_nxt : 0][r];
+    const int32_t idn = k_nxt >= 0 ? id_nxt : -1;
+    gather(idn, a_nxt);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float av = id_cur >= 0 ? a_cur[jg][e] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[jg][nt][e], acc[nt], 0, 0, 0);
+      }
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg) a_cur[jg] = a_nxt[jg];
+    id_cur = idn;
+    k_cur = k_nxt;
+    k_nxt = pop();
+  }
+
+  // epilogue: C layout col = lane&15, row = 4*(lane>>4) + e ; optional y = acc*scale + shift, ReLU
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = 16 * nt + r;
+    const float sc = scale ? scale[col] : 1.0f;
+    const float sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t orow = row_base + 4 * q + e;
+      if (orow < nlive) {
+        float v = acc[nt][e];
+        if (scale || shift) v = v * sc + sh;
+        if (relu) v = v > 0.f ? v : 0.f;
+        dst[orow * CD + col] = v;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- MFMA implicit GEMM, weights through LDS
 // In-kernel stamps on k_conv_mfma (tools/conv_diag.py, 64->64, 82k rows): a wave spends ~13,000 cycles per (tile, offset)
 // unit against 2,048 cycles of MFMA; the time goes into waiting for memory, and the traffic that congests it is the
@@ -736,6 +847,18 @@ static int launch_mfma(const float* src, const float* wp, const int32_t* pair, i
       hipLaunchKernelGGL((k_conv_mfma_cp<CS, CD, NTW>), dim3(nb), dim3(256), 0, s, src, wp, pair, ld, K, flip, n, d_n,
                          scale, shift, relu, dst);
       return SPX_OK;
+    }
+  }
+  {
+    int use_sm = 1;
+    if (const char* e = getenv("SPX_CONV_SM")) use_sm = atoi(e);    // dev override: 0 = one-load-per-group kernel
+    if constexpr (CS * CD <= 2048) {
+      if (use_sm && n < (int64_t(1) << 18)) {
+        int64_t waves1 = (n + 15) / 16;
+        hipLaunchKernelGGL((k_conv_mfma_sm<CS, CD>), dim3((unsigned)((waves1 + 3) / 4)), dim3(256), 0, s, src, wp, pair, ld, K,
+                           flip, n, d_n, scale, shift, relu, dst);
+        return SPX_OK;
+      }
     }
   }
   // rows per wave = 16*MT.  Measured on MI355X (tools/kbench.py): at KITTI/Waymo sizes (<= ~260k rows) the chip is
