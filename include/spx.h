@@ -92,6 +92,27 @@ int spx_mean_vfe(const float *voxels, const int32_t *num_points, int64_t n, cons
                  int c, float *out, spx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 1b. Dynamic voxelisation + mean (SURVEY.md §8a row a5')
+ *    replaces: DynamicMeanVFE.forward, pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:38-76
+ *      (torch.floor((xyz - range_min) / voxel_size).int(), in-range mask, merge key, torch.unique, scatter_mean).
+ *    Every in-range point is kept (no per-voxel / per-frame caps).  Voxels = unique cells in ASCENDING key
+ *      ((b*X + cx)*Y + cy)*Z + cz  (the order torch.unique yields in the reference).
+ *      points          device [n_points, stride] f32; column batch_col = frame index (or -1: single frame), columns
+ *                      [xyz_col, xyz_col + num_features) = x, y, z, extra features
+ *      voxel_features  device [cap, num_features] f32 : mean of those columns over the voxel's points, summed in point
+ *                      order (the reference sums with float atomics; this is bitwise reproducible)
+ *      voxel_coords    device [cap, 4] int32 (b, z, y, x)  -- the column order the reference returns (:72)
+ *      point_to_voxel  device [n_points] int32 : voxel row of every point (torch.unique's inverse), -1 if dropped
+ *      d_num_voxels    device int64 : number of voxels (may exceed cap: rows beyond cap are dropped)
+ *      grid3 = (X, Y, Z) cells; range6 = (xmin, ymin, zmin, xmax, ymax, zmax); voxel_size3 = (vx, vy, vz)
+ * ---------------------------------------------------------------------------------------------- */
+size_t spx_dynamic_voxelize_ws_bytes(int64_t n_points, int batch, const int32_t *grid3, int64_t cap);
+int spx_dynamic_voxelize(const float *points, int64_t n_points, int stride, int batch_col, int xyz_col, int num_features,
+                         const float *range6, const float *voxel_size3, const int32_t *grid3, int batch,
+                         float *voxel_features, int32_t *voxel_coords, int32_t *point_to_voxel, int64_t *d_num_voxels,
+                         int64_t cap, void *ws, size_t ws_bytes, spx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * 2. Submanifold rulebook (hash insert + kernel-offset probe)
  *    replaces: the indice-pair build inside spconv.pytorch.SubMConv3d.forward, reference call sites
  *      pcdet/models/backbones_3d/spconv_backbone.py:86,93,99-100,106-107,113-114 (indice_key subm1..4).

@@ -81,6 +81,39 @@ def voxelize(points, rng, vsize, max_points, max_voxels, c=None, xyz_col=0, feat
     return voxels[:m].copy(), coords[:m].copy(), num[:m].copy()
 
 
+def dynamic_voxelize(points, rng, vsize, batch_size=1, batch_col=0, xyz_col=1, num_features=None):
+    """DynamicMeanVFE.forward restated (reference pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:48-72): cells by
+    floor((xyz - range_min) / voxel_size) in fp32, in-range mask, merge key ((b*X + cx)*Y + cy)*Z + cz, unique (sorted),
+    per-voxel mean of the columns [xyz_col, xyz_col + C) — summed sequentially in point order in fp32 (the reference
+    sums with float atomics, so its own bits are not defined).  Returns features [M, C] f32,
+    coords [M, 4] int32 (b, z, y, x), inverse [N] int32 (-1 = dropped)."""
+    pts = np.ascontiguousarray(points, np.float32)
+    n, stride = pts.shape
+    c = (stride - xyz_col) if num_features is None else int(num_features)
+    lo = np.asarray(rng[:3], np.float32)
+    vs = np.asarray(vsize, np.float32)
+    grid = np.array([int(round((float(rng[3 + j]) - float(rng[j])) / float(vsize[j]))) for j in range(3)], np.int64)
+    f = np.floor((pts[:, xyz_col:xyz_col + 3] - lo) / vs)
+    b = pts[:, batch_col].astype(np.int64) if batch_col >= 0 else np.zeros(n, np.int64)
+    ok = np.all((f >= 0) & (f < grid.astype(np.float32)), axis=1) & (b >= 0) & (b < batch_size)
+    cell = f.astype(np.int64)
+    key = ((b * grid[0] + cell[:, 0]) * grid[1] + cell[:, 1]) * grid[2] + cell[:, 2]
+    uniq, inv_ok = np.unique(key[ok], return_inverse=True)
+    inverse = np.full(n, -1, np.int32)
+    inverse[ok] = inv_ok.astype(np.int32)
+    m = uniq.shape[0]
+    sums = np.zeros((m, c), np.float32)
+    np.add.at(sums, inv_ok, pts[ok][:, xyz_col:xyz_col + c])      # unbuffered: sequential in point order
+    counts = np.bincount(inv_ok, minlength=m).astype(np.float32)
+    feats = sums * (np.float32(1.0) / counts)[:, None]
+    z = uniq % grid[2]
+    y = (uniq // grid[2]) % grid[1]
+    x = (uniq // (grid[2] * grid[1])) % grid[0]
+    bb = uniq // (grid[2] * grid[1] * grid[0])
+    coords = np.stack([bb, z, y, x], 1).astype(np.int32)
+    return feats.astype(np.float32), coords, inverse
+
+
 def mean_vfe(voxels, num):
     voxels = np.ascontiguousarray(voxels, np.float32)
     num = np.ascontiguousarray(num, np.int32)

@@ -67,6 +67,60 @@ def test_golden_dense_conv(path, orc):
     _close(dw.cpu().numpy(), d["dw"], tol=5e-5)
 
 
+# ------------------------------------------------------------------------------------------ dynamic voxelisation
+
+@pytest.mark.parametrize("cfg_id,nframes", [(0, 3), (2, 4)])
+def test_dynamic_voxelize_matches_oracle(cfg_id, nframes, orc):
+    """Row a5' (DynamicMeanVFE): unique cells in key order, coords (b, z, y, x), point -> voxel map: exact; per-voxel means
+    bit-exact as well (both sum in point order in fp32).  Includes out-of-range points and a point ON the upper bound."""
+    from pcdet_amd.datasets import synthetic as syn
+    from spx import ops
+    geom = syn.CONFIGS[cfg_id]["geom"]
+    rng, vs = geom["point_cloud_range"], geom["voxel_size"]
+    b = syn.make_batch(cfg_id, nframes)
+    pts = b["points"].copy()
+    extra = np.array([[0, rng[0] - 1.0, 0.0, 0.0, 0.5], [1, rng[3], 0.0, 0.0, 0.5], [0, 1.0, rng[4] + 5.0, 0.0, 0.1],
+                      [nframes - 1, 10.0, 1.0, rng[5], 0.2], [0, 10.0, 1.0, -1.0, 0.3], [0, 10.02, 1.01, -1.01, 0.7]], np.float32)
+    pts = np.concatenate([pts, extra[:, :pts.shape[1]]], 0)
+    rs = np.random.RandomState(3)
+    pts = pts[rs.permutation(pts.shape[0])]                     # frames interleaved: nothing relies on contiguity
+    f_o, c_o, inv_o = orc.dynamic_voxelize(pts, rng, vs, batch_size=nframes)
+    out = ops.dynamic_voxelize(torch.from_numpy(pts).to(_dev()), rng, vs, batch_size=nframes)
+    assert out["num_voxels"] == c_o.shape[0]
+    assert np.array_equal(out["coords"].cpu().numpy(), c_o)
+    assert np.array_equal(out["inverse"].cpu().numpy(), inv_o)
+    assert np.array_equal(out["features"].cpu().numpy(), f_o)
+    # keys ascending = the order torch.unique gives the reference
+    g = [int(round((rng[3 + j] - rng[j]) / vs[j])) for j in range(3)]
+    c = out["coords"].cpu().numpy().astype(np.int64)
+    key = ((c[:, 0] * g[0] + c[:, 3]) * g[1] + c[:, 2]) * g[2] + c[:, 1]
+    assert (np.diff(key) > 0).all()
+    # capped call: the count still reports every voxel, rows beyond the cap are dropped, mapped points say so
+    cap = c_o.shape[0] // 2
+    o2 = ops.dynamic_voxelize(torch.from_numpy(pts).to(_dev()), rng, vs, batch_size=nframes, max_voxels=cap)
+    assert int(o2["d_num_voxels"].item()) == c_o.shape[0] and o2["coords"].shape[0] == cap
+    assert np.array_equal(o2["features"].cpu().numpy(), f_o[:cap])
+    inv2 = o2["inverse"].cpu().numpy()
+    assert np.array_equal(inv2[inv_o < cap], inv_o[inv_o < cap]) and (inv2[inv_o >= cap] == -1).all()
+
+
+def test_dynamic_mean_vfe_module_and_empty_input():
+    from pcdet_amd.config import AttrDict
+    from pcdet_amd.datasets import SyntheticDataset
+    from pcdet_amd.models.backbones_3d.vfe import DynamicMeanVFE
+    from spx import ops
+    ds = SyntheticDataset(cfg_id=0)
+    vfe = DynamicMeanVFE(AttrDict(), 4, ds.voxel_size, ds.grid_size, ds.point_cloud_range)
+    b = ds.collate_batch([ds[0], ds[1]])
+    bd = vfe({"points": torch.from_numpy(b["points"]).to(_dev()), "batch_size": 2})
+    assert bd["voxel_features"].shape[1] == 4 and bd["voxel_coords"].shape == (bd["voxel_features"].shape[0], 4)
+    assert vfe.get_output_feature_dim() == 4 and bd["voxel_coords"].dtype == torch.int32
+    far = torch.full((7, 5), 1e6, device=_dev())
+    far[:, 0] = 0
+    out = ops.dynamic_voxelize(far, ds.point_cloud_range, ds.voxel_size, batch_size=1)
+    assert out["num_voxels"] == 0 and (out["inverse"] == -1).all()
+
+
 # ------------------------------------------------------------------------------------------ rulebooks
 
 def _frame_indices(orc, cfg_id, nframes):

@@ -111,3 +111,29 @@ def test_oracle_rotated_iou_known_answers(orc):
     assert orc.nms_bev(boxes, 0.5).tolist() == [0, 2, 4]
     assert orc.nms_bev(boxes, 0.99).tolist() == [0, 1, 2, 3, 4]
     assert orc.nms_bev(boxes[:0], 0.5).tolist() == []
+
+
+def test_dynamic_voxelize_oracle_against_torch_unique():
+    """Row a5': the oracle's dynamic voxelisation against the reference's formulation written with stock torch ops on the
+    CPU (torch.floor / torch.unique / index_add_ in place of torch_scatter.scatter_mean, which is not installed): keys,
+    coords and inverse exactly; means to fp32 round-off."""
+    import torch
+    from oracle import oracle as orc
+    from pcdet_amd.datasets import synthetic
+    b = synthetic.make_batch(0, 3)
+    pts = torch.from_numpy(b["points"])
+    geom = synthetic.CONFIGS[0]["geom"]
+    rng, vs = geom["point_cloud_range"], geom["voxel_size"]
+    grid = torch.tensor([int(round((rng[3 + j] - rng[j]) / vs[j])) for j in range(3)])
+    pc = torch.floor((pts[:, 1:4] - torch.tensor(rng[:3])) / torch.tensor(vs)).int()          # dynamic_mean_vfe.py:51
+    mask = ((pc >= 0) & (pc < grid)).all(dim=1)                                                # :52
+    p2, pc2 = pts[mask], pc[mask].long()
+    merge = p2[:, 0].long() * int(grid.prod()) + pc2[:, 0] * int(grid[1] * grid[2]) + pc2[:, 1] * int(grid[2]) + pc2[:, 2]
+    unq, inv, cnt = torch.unique(merge, return_inverse=True, return_counts=True)               # :59
+    mean = torch.zeros(unq.shape[0], 4).index_add_(0, inv, p2[:, 1:]) / cnt[:, None]           # scatter_mean, :61
+    coords = torch.stack((unq // int(grid.prod()), (unq % int(grid.prod())) // int(grid[1] * grid[2]),
+                          (unq % int(grid[1] * grid[2])) // int(grid[2]), unq % int(grid[2])), 1)[:, [0, 3, 2, 1]]  # :64-68
+    f, c, inverse = orc.dynamic_voxelize(b["points"], rng, vs, batch_size=3)
+    assert np.array_equal(c, coords.int().numpy())
+    assert np.array_equal(inverse[mask.numpy()], inv.int().numpy()) and (inverse[~mask.numpy()] == -1).all()
+    assert np.abs(f - mean.numpy()).max() < 1e-5

@@ -400,3 +400,209 @@ extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }
+
+// ================================================================================================
+// Dynamic voxelisation + mean (SURVEY.md §8a row a5'): replaces DynamicMeanVFE.forward, reference
+// pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:38-76 — every in-range point is kept (no per-voxel or per-frame
+// caps), voxels are the UNIQUE cells sorted by the key ((b*X + cx)*Y + cy)*Z + cz (what torch.unique returns there),
+// the feature of a voxel is the mean of its points' columns [xyz_col, xyz_col + C), coords come back as (b, z, y, x).
+// No sort: the cells are marked in a bitmap laid out in key order and ranked by the popcount scan used for the strided
+// rulebook.  The reference sums with float atomics (torch_scatter); here the points of a voxel are bucketed (counting
+// sort), ordered by point index inside the bucket and summed in that order: bitwise reproducible.
+namespace {
+
+struct DynGeom {
+  float lo[3], vs[3];
+  int32_t grid[3];   // x, y, z
+};
+
+__device__ __forceinline__ int64_t dyn_key(const float* __restrict__ p, int batch_col, int xyz_col, int batch,
+                                           const DynGeom& g) {
+  // floor((p - lo) / vs) in fp32, like torch.floor((points[:, 1:4] - range[0:3]) / voxel_size).int()
+  int c[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float f = floorf(__fdiv_rn(__fsub_rn(p[xyz_col + j], g.lo[j]), g.vs[j]));
+    if (!(f >= 0.f) || !(f < (float)g.grid[j])) return -1;
+    c[j] = (int)f;
+  }
+  const int b = batch_col >= 0 ? (int)p[batch_col] : 0;
+  if (b < 0 || b >= batch) return -1;
+  return (((int64_t)b * g.grid[0] + c[0]) * g.grid[1] + c[1]) * g.grid[2] + c[2];
+}
+
+__global__ void k_dyn_mark(const float* __restrict__ pts, int64_t n, int stride, int batch_col, int xyz_col, int batch,
+                           DynGeom g, uint64_t* __restrict__ bits, int64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t key = dyn_key(pts + i * stride, batch_col, xyz_col, batch, g);
+  keys[i] = key;
+  if (key >= 0) atomicOr(reinterpret_cast<unsigned long long*>(&bits[key >> 6]), 1ull << (key & 63));
+}
+
+// rank of every point's voxel (-1 for dropped points) and the number of points per voxel
+__global__ void k_dyn_rank(const int64_t* __restrict__ keys, int64_t n, const uint64_t* __restrict__ bits,
+                           const uint32_t* __restrict__ prefix, int64_t cap, int32_t* __restrict__ inv,
+                           int32_t* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t key = keys[i];
+  int32_t rk = -1;
+  if (key >= 0) {
+    const uint64_t w = bits[key >> 6];
+    const int64_t r = (int64_t)prefix[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1ull));
+    if (r < cap) {
+      rk = (int32_t)r;
+      atomicAdd(&count[rk], 1);
+    }
+  }
+  inv[i] = rk;
+}
+
+// single block: offsets = exclusive scan of count[0..nv)
+__global__ void k_dyn_offsets(const int32_t* __restrict__ count, const int64_t* __restrict__ d_nv, int64_t cap,
+                              int32_t* __restrict__ offset) {
+  __shared__ uint32_t carry_s;
+  int64_t nv = *d_nv;
+  if (nv > cap) nv = cap;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nv; base += kBlock) {
+    const int64_t j = base + threadIdx.x;
+    const uint32_t v = j < nv ? (uint32_t)count[j] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, &total);
+    const uint32_t carry = carry_s;
+    if (j < nv) offset[j] = (int32_t)(carry + ex);
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+}
+
+__global__ void k_dyn_bucket(const int32_t* __restrict__ inv, int64_t n, const int32_t* __restrict__ offset,
+                             int32_t* __restrict__ cursor, int32_t* __restrict__ bucket) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int32_t rk = inv[i];
+  if (rk < 0) return;
+  bucket[offset[rk] + atomicAdd(&cursor[rk], 1)] = (int32_t)i;
+}
+
+// one thread per voxel: order its bucket by point index (insertion sort; buckets are a handful of points), sum in
+// that order, divide; coords (b, x, y, z) -> (b, z, y, x)
+__global__ void k_dyn_mean(const float* __restrict__ pts, int stride, int xyz_col, int C, const int64_t* __restrict__ d_nv,
+                           int64_t cap, const int32_t* __restrict__ offset, const int32_t* __restrict__ count,
+                           int32_t* __restrict__ bucket, int32_t* __restrict__ coords, float* __restrict__ feats) {
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int64_t nv = *d_nv;
+  if (nv > cap) nv = cap;
+  if (v >= nv) return;
+  int32_t* b = bucket + offset[v];
+  const int m = count[v];
+  for (int i = 1; i < m; ++i) {
+    const int32_t x = b[i];
+    int j = i - 1;
+    while (j >= 0 && b[j] > x) {
+      b[j + 1] = b[j];
+      --j;
+    }
+    b[j + 1] = x;
+  }
+  const float inv_m = 1.0f / (float)m;
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+    for (int i = 0; i < m; ++i) s += pts[(int64_t)b[i] * stride + xyz_col + c];
+    feats[v * C + c] = s * inv_m;
+  }
+  const int4 o = reinterpret_cast<const int4*>(coords)[v];      // (b, x, y, z) from k_scan_expand
+  reinterpret_cast<int4*>(coords)[v] = make_int4(o.x, o.w, o.z, o.y);
+}
+
+struct DynWs {
+  uint64_t* bits;
+  uint32_t *prefix, *blocksum;
+  int64_t* keys;
+  int32_t *count, *offset, *cursor, *bucket;
+  int64_t nwords, nblk;
+  size_t total;
+};
+
+static DynWs dyn_layout(void* ws, int64_t n, int batch, const int32_t* grid, int64_t cap) {
+  DynWs r;
+  const int64_t cells = (int64_t)batch * grid[0] * grid[1] * grid[2];
+  r.nwords = (cells + 63) / 64;
+  r.nblk = (r.nwords + kWordsPerBlock - 1) / kWordsPerBlock;
+  char* p = reinterpret_cast<char*>(ws);
+  size_t o = 0;
+  r.bits = reinterpret_cast<uint64_t*>(p + o);
+  o += spx_align((size_t)r.nwords * 8);
+  r.prefix = reinterpret_cast<uint32_t*>(p + o);
+  o += spx_align((size_t)r.nwords * 4);
+  r.blocksum = reinterpret_cast<uint32_t*>(p + o);
+  o += spx_align((size_t)(r.nblk + 1) * 4);
+  r.keys = reinterpret_cast<int64_t*>(p + o);
+  o += spx_align((size_t)(n > 0 ? n : 1) * 8);
+  r.count = reinterpret_cast<int32_t*>(p + o);      // count and cursor are adjacent: one fill clears both
+  o += spx_align((size_t)cap * 4);
+  r.cursor = reinterpret_cast<int32_t*>(p + o);
+  o += spx_align((size_t)cap * 4);
+  r.offset = reinterpret_cast<int32_t*>(p + o);
+  o += spx_align((size_t)cap * 4);
+  r.bucket = reinterpret_cast<int32_t*>(p + o);
+  o += spx_align((size_t)(n > 0 ? n : 1) * 4);
+  r.total = o;
+  return r;
+}
+
+}  // namespace
+
+extern "C" size_t spx_dynamic_voxelize_ws_bytes(int64_t n_points, int batch, const int32_t* grid, int64_t cap) {
+  if (!grid || batch <= 0 || cap <= 0) return 0;
+  return dyn_layout(nullptr, n_points, batch, grid, cap).total;
+}
+
+extern "C" int spx_dynamic_voxelize(const float* points, int64_t n_points, int stride, int batch_col, int xyz_col,
+                                    int num_features, const float* range6, const float* voxel_size3, const int32_t* grid3,
+                                    int batch, float* voxel_features, int32_t* voxel_coords, int32_t* point_to_voxel,
+                                    int64_t* d_num_voxels, int64_t cap, void* ws, size_t ws_bytes, spx_stream_t stream) {
+  if ((!points && n_points > 0) || !range6 || !voxel_size3 || !grid3 || !voxel_features || !voxel_coords ||
+      !point_to_voxel || !d_num_voxels || n_points < 0 || stride <= 0 || xyz_col < 0 || num_features < 3 ||
+      xyz_col + num_features > stride || batch_col >= stride || batch <= 0 || cap <= 0)
+    return SPX_ERR_INVALID_ARG;
+  for (int j = 0; j < 3; ++j)
+    if (grid3[j] <= 0 || !(voxel_size3[j] > 0.f)) return SPX_ERR_INVALID_ARG;
+  if (n_points >= (int64_t(1) << 31) || cap >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
+  if ((int64_t)batch * grid3[0] * grid3[1] * grid3[2] >= (int64_t(1) << 40)) return SPX_ERR_TOO_LARGE;
+  if (!ws || ws_bytes < spx_dynamic_voxelize_ws_bytes(n_points, batch, grid3, cap)) return SPX_ERR_WORKSPACE;
+  hipStream_t s = spx_s(stream);
+  DynWs w = dyn_layout(ws, n_points, batch, grid3, cap);
+  DynGeom g;
+  for (int j = 0; j < 3; ++j) {
+    g.lo[j] = range6[j];
+    g.vs[j] = voxel_size3[j];
+    g.grid[j] = grid3[j];
+  }
+  spx_fill_async(w.bits, 0, (size_t)w.nwords * 8, s);
+  spx_fill_async(w.count, 0, (size_t)((char*)w.offset - (char*)w.count), s);   // count + cursor
+  const unsigned nbp = (unsigned)((n_points + kBlock - 1) / kBlock);
+  if (n_points > 0)
+    hipLaunchKernelGGL(k_dyn_mark, dim3(nbp), dim3(kBlock), 0, s, points, n_points, stride, batch_col, xyz_col, batch, g,
+                       w.bits, w.keys);
+  hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, w.blocksum, w.nblk, d_num_voxels);
+  Int3 shape;
+  shape.v[0] = grid3[0], shape.v[1] = grid3[1], shape.v[2] = grid3[2];
+  hipLaunchKernelGGL(k_scan_expand, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum, w.prefix, shape,
+                     voxel_coords, cap);
+  if (n_points > 0) {
+    hipLaunchKernelGGL(k_dyn_rank, dim3(nbp), dim3(kBlock), 0, s, w.keys, n_points, w.bits, w.prefix, cap, point_to_voxel,
+                       w.count);
+    hipLaunchKernelGGL(k_dyn_offsets, dim3(1), dim3(kBlock), 0, s, w.count, d_num_voxels, cap, w.offset);
+    hipLaunchKernelGGL(k_dyn_bucket, dim3(nbp), dim3(kBlock), 0, s, point_to_voxel, n_points, w.offset, w.cursor, w.bucket);
+    hipLaunchKernelGGL(k_dyn_mean, dim3((unsigned)((cap + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, points, stride, xyz_col,
+                       num_features, d_num_voxels, cap, w.offset, w.count, w.bucket, voxel_coords, voxel_features);
+  }
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}

@@ -100,6 +100,40 @@ def voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels, batc
                 mean=None if mean is None else mean[:m], num_voxels=m, d_num_voxels=d_m, grid_size=grid)
 
 
+def dynamic_voxelize(points, point_cloud_range, voxel_size, batch_size=1, batch_col=0, xyz_col=1, num_features=None,
+                     max_voxels=None, sync=True):
+    """Dynamic voxelisation + per-voxel mean (include/spx.h §1b; reference DynamicMeanVFE.forward).  Returns
+    dict(features [M, C], coords [M, 4] (b, z, y, x), inverse [N] (voxel row of each point, -1 = out of range),
+    num_voxels, d_num_voxels).  Voxels are sorted by the key ((b*X + cx)*Y + cy)*Z + cz."""
+    _need_gpu(points)
+    lib = _lib.load()
+    points = points.contiguous().float()
+    n, stride = points.shape
+    c = (stride - xyz_col) if num_features is None else int(num_features)
+    rng = [float(x) for x in point_cloud_range]
+    vs = [float(x) for x in voxel_size]
+    grid = [int(round((rng[3 + j] - rng[j]) / vs[j])) for j in range(3)]
+    cap = max(1, n if max_voxels is None else min(n, int(max_voxels)))
+    dev = points.device
+    feats = torch.empty((cap, c), dtype=torch.float32, device=dev)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    inv = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    d_num = torch.zeros((1,), dtype=torch.int64, device=dev)
+    g3 = i3(grid)
+    wsb = lib.spx_dynamic_voxelize_ws_bytes(n, batch_size, g3, cap)
+    ws = workspace(dev, wsb)
+    check(lib.spx_dynamic_voxelize(_ptr(points), n, stride, batch_col, xyz_col, c, f_arr(rng), f_arr(vs), g3, batch_size,
+                                   _ptr(feats), _ptr(coords), _ptr(inv), _ptr(d_num), cap, _ptr(ws), wsb, _stream(points)),
+          "spx_dynamic_voxelize")
+    out = {"d_num_voxels": d_num, "grid_size": grid}
+    if sync:
+        m = min(int(d_num.item()), cap)
+        out.update(features=feats[:m], coords=coords[:m], inverse=inv[:n], num_voxels=m)
+    else:
+        out.update(features=feats, coords=coords, inverse=inv[:n], num_voxels=None)
+    return out
+
+
 def mean_vfe(voxels, num_points):
     _need_gpu(voxels, num_points)
     lib = _lib.load()
