@@ -385,6 +385,30 @@ def test_unetv2_forward_backward_parity():
         assert p.grad is not None and _rel(p.grad, q.grad) < 1e-3, n
 
 
+def test_data_processor_voxelises_like_the_oracle(orc=None):
+    """Rows a1/a2: DataProcessor.transform_points_to_voxels (VoxelGeneratorWrapper -> Point2VoxelCPU3d -> libspx) on one
+    frame against the oracle voxeliser; use_lead_xyz=False drops the xyz columns."""
+    from oracle import oracle as orc_mod
+    from pcdet_amd.config import AttrDict
+    from pcdet_amd.datasets import synthetic
+    from pcdet_amd.datasets.processor.data_processor import DataProcessor
+    geom = synthetic.CONFIGS[0]["geom"]
+    steps = [AttrDict(NAME="mask_points_and_boxes_outside_range", REMOVE_OUTSIDE_BOXES=True),
+             AttrDict(NAME="transform_points_to_voxels", VOXEL_SIZE=geom["voxel_size"], MAX_POINTS_PER_VOXEL=5,
+                      MAX_NUMBER_OF_VOXELS={"train": 16000, "test": 40000})]
+    dp = DataProcessor(steps, geom["point_cloud_range"], training=True, num_point_features=4)
+    pts = synthetic.make_frame(0, 3)["points"]
+    out = dp.forward({"points": pts.copy(), "use_lead_xyz": True})
+    keep = (pts[:, 0] >= geom["point_cloud_range"][0]) & (pts[:, 0] <= geom["point_cloud_range"][3] - 0.0002) & \
+           (pts[:, 1] >= geom["point_cloud_range"][1]) & (pts[:, 1] <= geom["point_cloud_range"][4] - 0.0002) & \
+           (pts[:, 2] >= geom["point_cloud_range"][2]) & (pts[:, 2] <= geom["point_cloud_range"][5] - 0.0002)
+    v, c, n = orc_mod.voxelize(pts[keep], geom["point_cloud_range"], geom["voxel_size"], 5, 16000)
+    assert np.array_equal(out["voxel_coords"], c) and np.array_equal(out["voxel_num_points"], n)
+    assert np.array_equal(out["voxels"], v) and out["voxels"].shape[1:] == (5, 4)
+    out2 = dp.forward({"points": pts.copy(), "use_lead_xyz": False})
+    assert out2["voxels"].shape[1:] == (5, 1) and np.array_equal(out2["voxels"], v[..., 3:])
+
+
 def test_graphed_static_capacity_forward_matches_dynamic():
     """Sync-free, hipGraph-captured forward (device-side row counts, static capacities) against the ordinary dynamic
     forward: identical kernels on identical rows => bitwise identical sparse outputs, across replays with different

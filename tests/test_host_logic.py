@@ -89,3 +89,31 @@ def test_sparse_tensor_container_api():
         spx.SparseConvolution(2, 4, 4)
     with pytest.raises(NotImplementedError):
         spx.SubMConv3d(4, 4, 3, groups=2)
+
+
+def test_data_processor_host_steps():
+    """DataProcessor (reference data_processor.py:64-226) without a GPU: range mask, box mask, shuffle, grid size."""
+    from pcdet_amd.config import AttrDict, cfg_from_yaml_file
+    from pcdet_amd.datasets.processor.data_processor import DataProcessor
+    from pcdet_amd.utils import box_utils
+    cfg = cfg_from_yaml_file(os.path.join(CFG, "kitti_models", "second.yaml"), AttrDict())
+    pcr = cfg.DATA_CONFIG.POINT_CLOUD_RANGE
+    steps = [AttrDict(NAME="mask_points_and_boxes_outside_range", REMOVE_OUTSIDE_BOXES=True),
+             AttrDict(NAME="shuffle_points", SHUFFLE_ENABLED={"train": True, "test": False}),
+             AttrDict(NAME="transform_points_to_voxels_placeholder", VOXEL_SIZE=[0.05, 0.05, 0.1])]
+    dp = DataProcessor(steps, pcr, training=True, num_point_features=4)
+    assert list(dp.grid_size) == [1408, 1600, 40] and dp.voxel_size == [0.05, 0.05, 0.1]
+    pts = np.array([[1.0, 0.0, 0.0, 0.5], [70.4, 0.0, 0.0, 0.5], [70.3997, 39.9997, 0.9997, 0.1], [-1.0, 0.0, 0.0, 0.2],
+                    [5.0, -40.0, -3.0, 0.3]], np.float32)
+    boxes = np.array([[10, 0, -1, 4, 2, 1.5, 0.3, 1], [200, 0, -1, 4, 2, 1.5, 0.0, 1], [70.0, 39.5, 0, 4, 2, 1.5, 0.7, 2]],
+                     np.float32)
+    np.random.seed(0)
+    out = dp.forward({"points": pts.copy(), "gt_boxes": boxes.copy(), "use_lead_xyz": True})
+    kept = out["points"]
+    assert kept.shape[0] == 3 and set(map(tuple, kept.tolist())) == set(map(tuple, pts[[0, 2, 4]].tolist()))
+    assert out["gt_boxes"].shape[0] == 2 and out["gt_boxes"][0, 0] == 10 and out["gt_boxes"][1, 0] == 70.0
+    c = box_utils.boxes_to_corners_3d(np.array([[0, 0, 0, 2, 4, 6, np.pi / 2]], np.float32))[0]
+    assert np.allclose(c[0], [-2, 1, -3], atol=1e-5) and np.allclose(c[6], [2, -1, 3], atol=1e-5)   # (+x,+y,-z) rotated 90 deg
+    test_dp = DataProcessor(steps, pcr, training=False, num_point_features=4)
+    out2 = test_dp.forward({"points": pts.copy(), "gt_boxes": boxes.copy(), "use_lead_xyz": True})
+    assert np.array_equal(out2["points"], pts[[0, 2, 4]]) and out2["gt_boxes"].shape[0] == 3     # no shuffle, boxes kept

@@ -27,3 +27,28 @@ def boxes3d_lidar_to_aligned_bev_boxes(boxes3d):
 
 def boxes3d_nearest_bev_iou(boxes_a, boxes_b):
     return boxes_iou_normal(boxes3d_lidar_to_aligned_bev_boxes(boxes_a), boxes3d_lidar_to_aligned_bev_boxes(boxes_b))
+
+
+def boxes_to_corners_3d(boxes3d):
+    """(N, 7) [x, y, z, dx, dy, dz, heading] -> (N, 8, 3) corners (reference pcdet/utils/box_utils.py:28-53, same corner
+    numbering: 0-3 bottom face counter-clockwise from (+x, +y), 4-7 the top face above them).  numpy in, numpy out."""
+    import numpy as np
+    is_numpy = isinstance(boxes3d, np.ndarray)
+    b = torch.as_tensor(boxes3d, dtype=torch.float32)
+    signs = b.new_tensor([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1],
+                          [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]]) * 0.5
+    local = b[:, None, 3:6] * signs[None]                                   # (N, 8, 3) in the box frame
+    cos, sin = torch.cos(b[:, 6])[:, None], torch.sin(b[:, 6])[:, None]
+    x = local[..., 0] * cos - local[..., 1] * sin
+    y = local[..., 0] * sin + local[..., 1] * cos
+    corners = torch.stack([x, y, local[..., 2]], dim=-1) + b[:, None, 0:3]
+    return corners.numpy() if is_numpy else corners
+
+
+def mask_boxes_outside_range_numpy(boxes, limit_range, min_num_corners=1):
+    """Keep boxes with at least `min_num_corners` corners inside the range (reference box_utils.py:56-72)."""
+    import numpy as np
+    limit_range = np.asarray(limit_range, dtype=np.float32)
+    corners = boxes_to_corners_3d(np.asarray(boxes)[:, 0:7])
+    inside = ((corners >= limit_range[0:3]) & (corners <= limit_range[3:6])).all(axis=2)
+    return inside.sum(axis=1) >= min_num_corners
