@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tsm-det-pointcloud-_amd")):
+for p in (ROOT, os.path.join(ROOT, "tsm-det-pointcloud-_amd"), os.path.join(ROOT, "tools")):
     sys.path.insert(0, p)
 
 
@@ -37,7 +37,7 @@ def main():
     import torch
     from spx import _lib
     _lib.LIB_PATH = lib_path
-    from oracle import oracle as orc
+    from kbench import backbone8x_layers
     from pcdet_amd.datasets import synthetic
     from spx import ops
     lib = _lib.load()
@@ -53,7 +53,7 @@ def main():
     shape = [int(gs[2]) + 1, int(gs[1]), int(gs[0])]
     idx = vox["coords"]
     books = {}
-    for name, cin, cout, ks, st, pd, ctype, key in orc.backbone8x_spec(geom["num_point_features"]):
+    for name, cin, cout, ks, st, pd, ctype, key in backbone8x_layers(geom["num_point_features"]):
         if key not in books:
             books[key] = ops.subm_rulebook(idx, batch, shape, ks) if ctype == "subm" else \
                 ops.conv_rulebook(idx, batch, shape, ks, st, pd)
