@@ -409,6 +409,37 @@ def test_data_processor_voxelises_like_the_oracle(orc=None):
     assert out2["voxels"].shape[1:] == (5, 1) and np.array_equal(out2["voxels"], v[..., 3:])
 
 
+def test_voxel_centroid_aggregation_matches_reference_vectors():
+    """Row f-2: get_overlapping_voxel_indices / get_centroid_per_voxel (spx_dynamic_voxelize underneath) against vectors
+    captured from the reference's voxel_aggregation_utils.py on the CPU (tests/golden/make_golden_voxel_agg.py):
+    indices, voxel order, counts and the point -> voxel map exactly; centroids to fp32 round-off."""
+    import spx
+    from pcdet_amd.utils import common_utils, voxel_aggregation_utils as agg
+    d = np.load(os.path.join(ROOT, "tests", "golden", "ref_voxel_agg.npz"))
+    dev = torch.device("cuda:0")
+    pts = torch.from_numpy(d["points"]).to(dev)
+    for ds in (1, 4):
+        vi = agg.get_overlapping_voxel_indices(pts[:, 1:4], ds, d["vs"].tolist(), d["pcr"].tolist())
+        assert np.array_equal(vi.cpu().numpy(), d["ovi_ds%d" % ds])
+    cen, cidx, cnt, inv = agg.get_centroid_per_voxel(torch.from_numpy(d["cpv_points"]).to(dev),
+                                                     torch.from_numpy(d["cpv_vidx"]).to(dev))
+    assert np.array_equal(cidx.cpu().numpy(), d["cpv_idx"]) and np.array_equal(cnt.cpu().numpy(), d["cpv_count"])
+    assert np.array_equal(inv.cpu().numpy(), d["cpv_inverse"])
+    assert np.abs(cen.cpu().numpy() - d["cpv_centroids"]).max() < 2e-6 * np.abs(d["cpv_centroids"]).max()
+    cen2, cidx2, cnt2, inv2 = agg.get_centroid_per_voxel(cen, torch.from_numpy(d["cpv2_vidx"]).to(dev), cnt)
+    assert np.array_equal(cidx2.cpu().numpy(), d["cpv2_idx"]) and np.array_equal(cnt2.cpu().numpy(), d["cpv2_count"])
+    assert np.array_equal(inv2.cpu().numpy(), d["cpv2_inverse"])
+    assert np.abs(cen2.cpu().numpy() - d["cpv2_centroids"]).max() < 5e-6 * np.abs(d["cpv2_centroids"]).max()
+    # voxel -> row table and the lookup built on it
+    idx = torch.tensor([[0, 1, 2, 3], [1, 0, 0, 5], [0, 4, 4, 4]], dtype=torch.int32, device=dev)
+    st = spx.SparseConvTensor(torch.zeros(3, 2, device=dev), idx, [5, 6, 7], 2)
+    table = common_utils.generate_voxel2pinds(st)
+    assert table.shape == (2, 5, 6, 7) and int(table[0, 1, 2, 3]) == 0 and int(table[1, 0, 0, 5]) == 1 and int((table >= 0).sum()) == 3
+    q = torch.tensor([[0, 4, 4, 4], [0, 0, 0, 0], [1, 0, 0, 5]], device=dev)
+    rows, hit = agg.get_nonempty_voxel_feature_indices(q, st)
+    assert rows.tolist() == [2, 1] and hit.tolist() == [True, False, True]
+
+
 def test_graphed_static_capacity_forward_matches_dynamic():
     """Sync-free, hipGraph-captured forward (device-side row counts, static capacities) against the ordinary dynamic
     forward: identical kernels on identical rows => bitwise identical sparse outputs, across replays with different

@@ -73,3 +73,18 @@ def init_dist_pytorch(tcp_port=None, local_rank=None, backend="nccl"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend=backend)
     return dist.get_world_size(), dist.get_rank()
+
+
+def scatter_point_inds(indices, point_inds, shape):
+    """Dense int32 table of `shape`, -1 everywhere except table[indices] = point_inds (reference spconv_utils.py)."""
+    table = torch.full(tuple(int(x) for x in shape), -1, dtype=point_inds.dtype, device=point_inds.device)
+    table[tuple(indices[:, j] for j in range(indices.shape[1]))] = point_inds
+    return table
+
+
+def generate_voxel2pinds(sparse_tensor):
+    """[B, Z, Y, X] table: row of the active voxel at each cell, -1 elsewhere (reference common_utils.py:257-265); what
+    voxel_query and the voxel-centroid lookup index into."""
+    idx = sparse_tensor.indices.long()
+    rows = torch.arange(idx.shape[0], device=idx.device, dtype=torch.int32)
+    return scatter_point_inds(idx, rows, [sparse_tensor.batch_size] + list(sparse_tensor.spatial_shape))
