@@ -282,6 +282,21 @@ int spx_bn_relu_bwd(const float *x, const float *dy, int64_t n, int c, const flo
                     const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma, float *dbeta,
                     void *ws, size_t ws_bytes, spx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * 10. Voxel query (consumers of multi_scale_3d_features)
+ *    replaces: pointnet2_stack_cuda.voxel_query_wrapper, reference
+ *      pcdet/ops/pointnet2/pointnet2_stack/src/voxel_query_gpu.cu:10-122 (python side voxel_query_utils.py:12-50).
+ *      new_xyz [m,3] f32 query centres; xyz [n,3] f32 positions of the rows; new_coords [m,4] int32 (b, z, y, x);
+ *      point_indices [batch, Z, Y, X] int32 = row at each cell or -1 (generate_voxel2pinds); shape3 = (Z, Y, X);
+ *      range3 = (z_range, y_range, x_range) cells scanned each way; idx [m, nsample] int32 out (slot 0 = -1 for an
+ *      empty ball, exactly as the reference kernel leaves it); cnt_unique [m] = occupied cells scanned.
+ *    The reservoir step that applies once more than nsample neighbours lie within the radius uses cuRAND's XORWOW
+ *    algorithm seeded with the query index like the reference; that stream is parity-unpinned here (csrc/voxel_query.hip).
+ * ---------------------------------------------------------------------------------------------- */
+int spx_voxel_query(const float *new_xyz, const float *xyz, const int32_t *new_coords, const int32_t *point_indices,
+                    int64_t m, int batch, const int32_t *shape3, int nsample, float radius, const int32_t *range3,
+                    int32_t *idx, int32_t *cnt_unique, spx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

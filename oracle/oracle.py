@@ -291,3 +291,20 @@ def nms_bev(boxes_sorted, thresh, axis_aligned=False):
     n = lib().orc_nms_bev(_f(b), ctypes.c_int64(b.shape[0]), ctypes.c_float(thresh), int(axis_aligned),
                           keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
     return keep[:n].copy()
+
+
+def voxel_query(new_xyz, xyz, new_coords, point_indices, nsample, radius, ranges):
+    """voxel_query_kernel_stack restated (reference voxel_query_gpu.cu:10-100; oracle/spx_oracle.c: the reservoir step's
+    generator is PARITY UNPINNED).  Returns idx [M, nsample] int32 (raw: -1 in slot 0 for empty balls) and the number of
+    occupied cells scanned per query."""
+    q = np.ascontiguousarray(new_xyz, np.float32)
+    p = np.ascontiguousarray(xyz, np.float32)
+    c = np.ascontiguousarray(new_coords, np.int32)
+    t = np.ascontiguousarray(point_indices, np.int32)
+    m = q.shape[0]
+    idx = np.zeros((max(m, 1), nsample), np.int32)
+    cnt = np.zeros((max(m, 1),), np.int32)
+    _b, r1, r2, r3 = t.shape
+    lib().orc_voxel_query(_f(q), _f(p), _i(c), _i(t), ctypes.c_int64(m), int(r1), int(r2), int(r3), int(nsample),
+                          ctypes.c_float(radius), int(ranges[0]), int(ranges[1]), int(ranges[2]), _i(idx), _i(cnt))
+    return idx[:m], cnt[:m]

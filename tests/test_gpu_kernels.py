@@ -362,6 +362,54 @@ def _rel_t(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12))
 
 
+# ------------------------------------------------------------------------------------------ voxel query (row f-4)
+
+@pytest.mark.parametrize("nsample,ranges,radius", [(16, (1, 1, 1), 0.4), (4, (2, 3, 3), 1.0), (32, (1, 4, 4), 5.0)])
+def test_voxel_query_matches_oracle(nsample, ranges, radius, orc):
+    """spx_voxel_query against the oracle restatement of voxel_query_kernel_stack on the conv3-level voxels of two
+    synthetic frames: index lists (including the fork's reservoir replacement once a ball overflows), empty-ball marker
+    and occupied-cell counts — exact.  (The reservoir's random stream itself is parity-unpinned, see csrc/voxel_query.hip.)"""
+    import spx
+    from pcdet_amd.ops.pointnet2.pointnet2_stack import voxel_query_utils as vq
+    from pcdet_amd.utils import common_utils
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, 0, 2)
+    dev = _dev()
+    st = spx.SparseConvTensor(torch.zeros(idx_np.shape[0], 1, device=dev), torch.from_numpy(idx_np).to(dev), shape, 2)
+    table = common_utils.generate_voxel2pinds(st)
+    centers = common_utils.get_voxel_centers(st.indices[:, 1:], 1, [0.05, 0.05, 0.1], [0, -8, -3, 12.8, 8, 1]).contiguous()
+    g = torch.Generator().manual_seed(5)
+    pick = torch.randperm(idx_np.shape[0], generator=g)[:1500].to(dev)
+    q_xyz = (centers[pick] + 0.01).contiguous()
+    q_coords = st.indices[pick].clone()
+    q_coords[:7, 1:] = torch.tensor([0, 0, 0], dtype=torch.int32, device=dev)        # corner queries: clipped scan
+    idx, cnt = ops.voxel_query(q_xyz, centers, q_coords, table, nsample, radius, ranges)
+    idx_o, cnt_o = orc.voxel_query(q_xyz.cpu().numpy(), centers.cpu().numpy(), q_coords.cpu().numpy(), table.cpu().numpy(),
+                                   nsample, radius, ranges)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    assert np.array_equal(idx.cpu().numpy(), idx_o)
+    assert (cnt_o > 0).any() and ((idx_o[:, 0] == -1).any() or radius > 1)
+    # python wrapper: empty balls -> zeros + mask, density in (0, 1]
+    i2, empty, dens = vq.voxel_query(ranges, radius, nsample, centers, q_xyz, q_coords, table)
+    assert torch.equal(empty.cpu(), torch.from_numpy(idx_o[:, 0] == -1)) and int(i2.min()) >= 0
+    vol = (2 * ranges[0] + 1) * (2 * ranges[1] + 1) * (2 * ranges[2] + 1)
+    assert torch.allclose(dens.cpu().view(-1), torch.from_numpy(cnt_o).float() / vol)
+    # grouping: features gathered through the lists, frame-local indexing
+    feats = torch.randn(idx_np.shape[0], 8, generator=g).to(dev)
+    nb = torch.bincount(st.indices[:, 0].long(), minlength=2)
+    order = torch.argsort(q_coords[:, 0].long(), stable=True)                        # queries grouped by frame
+    mod = vq.VoxelQueryAndGrouping(ranges, radius, nsample)
+    gf, gx, em, _ = mod(q_coords[order].contiguous(), centers, nb, q_xyz[order].contiguous(),
+                        torch.bincount(q_coords[:, 0].long(), minlength=2), feats, table)
+    assert gf.shape == (1500, 8, nsample) and gx.shape == (1500, 3, nsample)
+    idx_r, _ = orc.voxel_query(q_xyz[order].cpu().numpy(), centers.cpu().numpy(), q_coords[order].cpu().numpy(),
+                               table.cpu().numpy(), nsample, radius, ranges)     # the reservoir is seeded by the query's position
+    ref_rows = torch.from_numpy(idx_r).to(dev).long()
+    ref_rows[em] = 0
+    nonempty = ~em
+    assert torch.equal(gf[nonempty], feats[ref_rows[nonempty]].permute(0, 2, 1))
+
+
 # ------------------------------------------------------------------------------------------ densify
 
 @pytest.mark.parametrize("channels_last", [False, True])

@@ -458,3 +458,21 @@ def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu):
                               int(bool(relu)), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream(x)),
           "spx_bn_relu_bwd")
     return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------- voxel query (row f-4)
+
+def voxel_query(new_xyz, xyz, new_coords, point_indices, nsample, radius, ranges):
+    """Raw kernel result of include/spx.h §10: idx [M, nsample] int32 (slot 0 = -1 for empty balls) and cnt [M]."""
+    _need_gpu(new_xyz, xyz, new_coords, point_indices)
+    lib = _lib.load()
+    new_xyz, xyz = new_xyz.contiguous().float(), xyz.contiguous().float()
+    new_coords, point_indices = new_coords.contiguous().int(), point_indices.contiguous().int()
+    m = new_coords.shape[0]
+    b, z, y, x = point_indices.shape
+    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
+    cnt = torch.zeros((m,), dtype=torch.int32, device=xyz.device)
+    check(lib.spx_voxel_query(_ptr(new_xyz), _ptr(xyz), _ptr(new_coords), _ptr(point_indices), m, b, i3([z, y, x]),
+                              int(nsample), float(radius), i3(ranges), _ptr(idx), _ptr(cnt), _stream(xyz)),
+          "spx_voxel_query")
+    return idx, cnt
