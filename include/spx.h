@@ -282,6 +282,16 @@ int spx_bn_relu_bwd(const float *x, const float *dy, int64_t n, int c, const flo
                     const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma, float *dbeta,
                     void *ws, size_t ws_bytes, spx_stream_t stream);
 
+/* y = relu(bn(x) + res): the tail of SparseBasicBlock (reference spconv_backbone.py:56-72: bn2, `out.features +
+ * identity.features`, ReLU; SURVEY.md §8 row f-3 "fused residual add epilogue").  res [n, c] or NULL (= spx_bn_relu_*);
+ * backward also writes dres [n, c] (may be NULL) = dy masked by the ReLU, the gradient of the identity branch. */
+int spx_bn_add_relu_fwd(const float *x, const float *res, int64_t n, const int64_t *d_n, int c, const float *gamma,
+                        const float *beta, float *running_mean, float *running_var, float momentum, float eps, int relu,
+                        float *y, float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, spx_stream_t stream);
+int spx_bn_add_relu_bwd(const float *x, const float *res, const float *dy, int64_t n, int c, const float *gamma,
+                        const float *beta, const float *save_mean, const float *save_invstd, int relu, float *dx,
+                        float *dres, float *dgamma, float *dbeta, void *ws, size_t ws_bytes, spx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 10. Voxel query (consumers of multi_scale_3d_features)
  *    replaces: pointnet2_stack_cuda.voxel_query_wrapper, reference
@@ -296,6 +306,14 @@ int spx_bn_relu_bwd(const float *x, const float *dy, int64_t n, int c, const flo
 int spx_voxel_query(const float *new_xyz, const float *xyz, const int32_t *new_coords, const int32_t *point_indices,
                     int64_t m, int batch, const int32_t *shape3, int nsample, float radius, const int32_t *range3,
                     int32_t *idx, int32_t *cnt_unique, spx_stream_t stream);
+
+/* replaces: pointnet2_stack_cuda.voxel_query_dilated_wrapper, reference voxel_query_gpu.cu:125-236 (python side
+ *   voxel_query_utils.py:117-158).  As spx_voxel_query, with the scan stepping by stride3 = (z, y, x) cells, neighbours
+ *   closer than former_radius dropped as well, and idx_cnt [m] = number of slots filled before padding (<= nsample). */
+int spx_voxel_query_dilated(const float *new_xyz, const float *xyz, const int32_t *new_coords,
+                            const int32_t *point_indices, int64_t m, int batch, const int32_t *shape3, int nsample,
+                            float former_radius, float radius, const int32_t *range3, const int32_t *stride3,
+                            int32_t *idx, int32_t *cnt_unique, int32_t *idx_cnt, spx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -308,3 +308,22 @@ def voxel_query(new_xyz, xyz, new_coords, point_indices, nsample, radius, ranges
     lib().orc_voxel_query(_f(q), _f(p), _i(c), _i(t), ctypes.c_int64(m), int(r1), int(r2), int(r3), int(nsample),
                           ctypes.c_float(radius), int(ranges[0]), int(ranges[1]), int(ranges[2]), _i(idx), _i(cnt))
     return idx[:m], cnt[:m]
+
+
+def voxel_query_dilated(new_xyz, xyz, new_coords, point_indices, nsample, former_radius, radius, ranges, strides):
+    """voxel_query_dilated_kernel_stack restated (reference voxel_query_gpu.cu:125-215; same PARITY UNPINNED generator).
+    Returns idx [M, nsample], cnt_unique [M], idx_cnt [M]."""
+    q = np.ascontiguousarray(new_xyz, np.float32)
+    p = np.ascontiguousarray(xyz, np.float32)
+    c = np.ascontiguousarray(new_coords, np.int32)
+    t = np.ascontiguousarray(point_indices, np.int32)
+    m = q.shape[0]
+    idx = np.zeros((max(m, 1), nsample), np.int32)
+    cnt = np.zeros((max(m, 1),), np.int32)
+    filled = np.zeros((max(m, 1),), np.int32)
+    _b, r1, r2, r3 = t.shape
+    lib().orc_voxel_query_dilated(_f(q), _f(p), _i(c), _i(t), ctypes.c_int64(m), int(r1), int(r2), int(r3), int(nsample),
+                                  ctypes.c_float(former_radius), ctypes.c_float(radius), int(ranges[0]), int(ranges[1]),
+                                  int(ranges[2]), int(strides[0]), int(strides[1]), int(strides[2]), _i(idx), _i(cnt),
+                                  _i(filled))
+    return idx[:m], cnt[:m], filled[:m]

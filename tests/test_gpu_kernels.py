@@ -410,6 +410,49 @@ def test_voxel_query_matches_oracle(nsample, ranges, radius, orc):
     assert torch.equal(gf[nonempty], feats[ref_rows[nonempty]].permute(0, 2, 1))
 
 
+@pytest.mark.parametrize("nsample,ranges,strides,former,radius", [(16, (2, 4, 4), (1, 2, 2), 0.2, 0.9),
+                                                                    (3, (2, 6, 6), (2, 3, 3), 0.0, 5.0),
+                                                                    (4, (1, 2, 2), (1, 1, 1), 0.0, 0.6)])
+def test_voxel_query_dilated_matches_oracle(nsample, ranges, strides, former, radius, orc):
+    """spx_voxel_query_dilated against the oracle restatement of voxel_query_dilated_kernel_stack: strided scan, the
+    inner-radius cut, filled-slot counts, padding and the overflow reservoir — exact.  Stride 1 with no inner radius
+    must give the plain kernel's lists."""
+    import spx
+    from pcdet_amd.ops.pointnet2.pointnet2_stack import voxel_query_utils as vq
+    from pcdet_amd.utils import common_utils
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, 0, 2)
+    dev = _dev()
+    st = spx.SparseConvTensor(torch.zeros(idx_np.shape[0], 1, device=dev), torch.from_numpy(idx_np).to(dev), shape, 2)
+    table = common_utils.generate_voxel2pinds(st)
+    centers = common_utils.get_voxel_centers(st.indices[:, 1:], 1, [0.05, 0.05, 0.1], [0, -8, -3, 12.8, 8, 1]).contiguous()
+    g = torch.Generator().manual_seed(9)
+    pick = torch.sort(torch.randperm(idx_np.shape[0], generator=g)[:1200]).values.to(dev)   # batch-major like the rows
+    q_xyz = (centers[pick] + 0.01).contiguous()
+    q_coords = st.indices[pick].clone()
+    idx, cnt, filled = ops.voxel_query_dilated(q_xyz, centers, q_coords, table, nsample, former, radius, ranges, strides)
+    idx_o, cnt_o, filled_o = orc.voxel_query_dilated(q_xyz.cpu().numpy(), centers.cpu().numpy(), q_coords.cpu().numpy(),
+                                                     table.cpu().numpy(), nsample, former, radius, ranges, strides)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o) and np.array_equal(filled.cpu().numpy(), filled_o)
+    assert np.array_equal(idx.cpu().numpy(), idx_o)
+    assert filled_o.max() == nsample or radius < 1                                    # the reservoir branch ran
+    if former > 0:
+        assert (idx_o[:, 0] != pick.cpu().numpy()).all()                             # the query's own voxel is cut
+    if strides == (1, 1, 1) and former == 0.0:
+        i_plain, c_plain = ops.voxel_query(q_xyz, centers, q_coords, table, nsample, radius, ranges)
+        assert torch.equal(i_plain, idx) and torch.equal(c_plain, cnt)
+    i2, empty, score = vq.voxel_query_dilated(ranges, strides, former, radius, nsample, centers, q_xyz, q_coords, table)
+    assert torch.equal(empty.cpu(), torch.from_numpy(idx_o[:, 0] == -1)) and int(i2.min()) >= 0
+    assert torch.allclose(score.cpu().view(-1), torch.clamp(torch.from_numpy(cnt_o).float() / nsample, max=1.0))
+    feats = torch.randn(idx_np.shape[0], 6, generator=g).to(dev)
+    nb = torch.bincount(st.indices[:, 0].long(), minlength=2)
+    mod = vq.VoxelQueryAndGroupingDilated(ranges, strides, former, radius, nsample)
+    gf, gx, em, _ = mod(q_coords, centers, nb, q_xyz, torch.bincount(q_coords[:, 0].long(), minlength=2), feats, table)
+    rows = torch.from_numpy(idx_o).to(dev).long()
+    rows[em] = 0
+    assert torch.equal(gf[~em], feats[rows[~em]].permute(0, 2, 1)) and torch.equal(gx[~em], centers[rows[~em]].permute(0, 2, 1))
+
+
 # ------------------------------------------------------------------------------------------ densify
 
 @pytest.mark.parametrize("channels_last", [False, True])
@@ -607,3 +650,42 @@ def test_fused_bn_relu_train_matches_torch(n, c, relu):
     # bitwise reproducible
     xm2 = x.clone().requires_grad_(True)
     assert torch.equal(F_.bn_relu_train(xm2, copy.deepcopy(ref), relu), ym)
+
+
+@pytest.mark.parametrize("n,c,relu", [(83083, 32, True), (40001, 64, True), (5000, 128, False)])
+def test_fused_bn_add_relu_train_matches_torch(n, c, relu):
+    """spx_bn_add_relu_* (the tail of SparseBasicBlock, reference spconv_backbone.py:56-72: bn2, + identity, ReLU) against
+    the torch modules in that order: output, running statistics, and the gradients of x, the identity branch, gamma and
+    beta.  The identity values are nudged away from exact cancellation so that both sides take the same ReLU branch."""
+    import copy
+    from spx import functional as F_
+    dev = _dev()
+    g = torch.Generator().manual_seed(3 * n + c)
+    x = (torch.randn(n, c, generator=g) * torch.linspace(0.5, 3.0, c) + torch.linspace(-2, 2, c)).to(dev)
+    res = torch.randn(n, c, generator=g).to(dev)
+    dy = torch.randn(n, c, generator=g).to(dev)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev).train()
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        ref.bias.copy_(torch.randn(c, generator=g) * 0.2)
+        z0 = copy.deepcopy(ref)(x) + res
+        res = torch.where(z0.abs() < 1e-3, res + 0.01, res)
+    mine = copy.deepcopy(ref)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    yr = ref(xr) + rr
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(dy)
+    xm, rm = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    ym = F_.bn_act(xm, mine, relu, rm)
+    ym.backward(dy)
+    _close(ym.detach().cpu().numpy(), yr.detach().cpu().numpy(), tol=2e-5)
+    _close(mine.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), tol=1e-6)
+    _close(mine.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), tol=1e-6)
+    assert torch.equal(rm.grad, rr.grad)                       # dy masked by the ReLU: no arithmetic, exact
+    _close(xm.grad.cpu().numpy(), xr.grad.cpu().numpy(), tol=5e-5)
+    _close(mine.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), tol=5e-5)
+    _close(mine.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), tol=5e-5)
+    # eval mode / CPU-side fallback of bn_act is the torch modules themselves
+    mine.eval()
+    with torch.no_grad():
+        assert torch.equal(F_.bn_act(x, mine, relu, res), torch.relu(mine(x) + res) if relu else mine(x) + res)

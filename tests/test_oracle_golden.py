@@ -137,3 +137,46 @@ def test_dynamic_voxelize_oracle_against_torch_unique():
     assert np.array_equal(c, coords.int().numpy())
     assert np.array_equal(inverse[mask.numpy()], inv.int().numpy()) and (inverse[~mask.numpy()] == -1).all()
     assert np.abs(f - mean.numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("strides,former", [((1, 1, 1), 0.0), ((1, 2, 2), 0.15), ((2, 3, 1), 0.0)])
+def test_voxel_query_oracle_against_bruteforce(strides, former, orc):
+    """The C restatement of voxel_query(_dilated)_kernel_stack (reference voxel_query_gpu.cu:10-100, 125-215) against a
+    direct numpy scan, with nsample larger than any ball so that no random number is drawn: neighbour lists in scan
+    order, first-neighbour padding, empty marker, occupied-cell and filled-slot counts."""
+    rng = np.random.default_rng(3)
+    B, Z, Y, X = 2, 5, 12, 12
+    occ = rng.random((B, Z, Y, X)) < 0.3
+    coords = np.argwhere(occ).astype(np.int32)                               # batch-major (b, z, y, x)
+    n = coords.shape[0]
+    table = np.full((B, Z, Y, X), -1, np.int32)
+    table[tuple(coords.T)] = np.arange(n, dtype=np.int32)
+    xyz = (coords[:, [3, 2, 1]].astype(np.float32) + 0.5) * np.float32(0.1)
+    q = rng.choice(n, 60, replace=False)
+    q_coords, q_xyz = coords[q], xyz[q] + np.float32(0.01)
+    ranges, radius, nsample = (2, 3, 3), np.float32(0.32), 400
+    idx, cnt, filled = orc.voxel_query_dilated(q_xyz, xyz, q_coords, table, nsample, former, radius, ranges, strides)
+    for i in range(len(q)):
+        b, z0, y0, x0 = q_coords[i]
+        found, scanned = [], 0
+        for dz in range(-ranges[0], ranges[0] + 1, strides[0]):
+            for dy in range(-ranges[1], ranges[1] + 1, strides[1]):
+                for dx in range(-ranges[2], ranges[2] + 1, strides[2]):
+                    z, y, x = z0 + dz, y0 + dy, x0 + dx
+                    if not (0 <= z < Z and 0 <= y < Y and 0 <= x < X) or table[b, z, y, x] < 0:
+                        continue
+                    scanned += 1
+                    d = xyz[table[b, z, y, x]] - q_xyz[i]
+                    d2 = np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+                    if d2 > radius * radius or d2 < np.float32(former) * np.float32(former):
+                        continue
+                    found.append(int(table[b, z, y, x]))
+        assert cnt[i] == scanned and filled[i] == len(found) < nsample
+        if found:
+            want = (found + found * (nsample // len(found) + 1))[:nsample]           # cyclic padding == idx[cnt] = idx[l]
+            assert idx[i].tolist() == want
+        else:
+            assert idx[i, 0] == -1 and (idx[i, 1:] == 0).all()             # the padding loop copies slot l onto itself
+    if strides == (1, 1, 1) and former == 0.0:
+        i_plain, c_plain = orc.voxel_query(q_xyz, xyz, q_coords, table, nsample, radius, ranges)
+        assert np.array_equal(i_plain, idx) and np.array_equal(c_plain, cnt)

@@ -9,6 +9,9 @@
 //   backward: k_bn_reduce<true> (sum dz, sum dz*xhat; the ReLU mask is RECOMPUTED from x, y is not read back) ->
 //             k_bn_bwd_finalize -> k_bn_bwd_apply (dx)
 // Partials are combined in a fixed order (no float atomics): bitwise reproducible.
+// With a residual (`res`, the identity branch of SparseBasicBlock, reference spconv_backbone.py:56-72: bn2, add, ReLU)
+// the same kernels compute y = relu(bn(x) + res) and, backward, hand the masked gradient to the identity branch (dres):
+// the add and the second ReLU cost no pass of their own.
 #include "spx_common.h"
 
 namespace {
@@ -29,12 +32,25 @@ __device__ __forceinline__ f32x4 bn_affine(f32x4 v, f32x4 mu, f32x4 is, f32x4 ga
   return o;
 }
 
+// bn_affine (+ residual element i when there is one): the pre-activation value of forward and backward alike
+__device__ __forceinline__ f32x4 bn_out(f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be, const float* __restrict__ res,
+                                        int64_t i) {
+  f32x4 o = bn_affine(v, mu, is, ga, be);
+  if (res) {
+    const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], r[e]);
+  }
+  return o;
+}
+
 // grid-stride over float4 elements of x[N][C]; because 256*4 % C == 0 is NOT assumed, each thread recomputes its channel
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ x, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ dy,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    int64_t n, const int64_t* d_n, int C, int relu,
+                                                   const float* __restrict__ res,
                                                    float* __restrict__ partial /*[grid][2][C]*/) {
   __shared__ float sm[256][8];   // per-thread partials (4 channels x {a, b})
   const int64_t nlive = spx_live_n(d_n, n);
@@ -61,7 +77,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ x, 
     } else {
       f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
       if (relu) {
-        const f32x4 o = bn_affine(v, mu, is, ga, be);
+        const f32x4 o = bn_out(v, mu, is, ga, be, res, i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
       }
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ pa
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, int64_t n, const int64_t* d_n, int C,
-                                                  int relu, float* __restrict__ y) {
+                                                  int relu, const float* __restrict__ res, float* __restrict__ y) {
   const int64_t total4 = spx_live_n(d_n, n) * C / 4;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
     f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
     f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
-    f32x4 o = bn_affine(v, mu, is, ga, be);
+    f32x4 o = bn_out(v, mu, is, ga, be, res, i);
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
@@ -162,7 +178,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ dy, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                      int64_t n, int C, int relu, float* __restrict__ dx) {
+                                                      int64_t n, int C, int relu, const float* __restrict__ res,
+                                                      float* __restrict__ dx, float* __restrict__ dres) {
   const int64_t total4 = n * C / 4;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const float invN = 1.0f / (float)n;
@@ -173,10 +190,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
     f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
     if (relu) {
-      const f32x4 o = bn_affine(v, mu, is, ga, *reinterpret_cast<const f32x4*>(beta + c0));
+      const f32x4 o = bn_out(v, mu, is, ga, *reinterpret_cast<const f32x4*>(beta + c0), res, i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
     }
+    if (dres) reinterpret_cast<f32x4*>(dres)[i] = g;
     f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c0), db = *reinterpret_cast<const f32x4*>(dbeta + c0);
     f32x4 xh = (v - mu) * is;
     reinterpret_cast<f32x4*>(dx)[i] = ga * is * (g - db * invN - xh * dg * invN);
@@ -196,9 +214,10 @@ static inline int bn_blocks(int64_t n, int C) {
 
 extern "C" size_t spx_bn_relu_ws_bytes(int c) { return spx_align((size_t)kMaxBlocks * 2 * c * 4); }
 
-extern "C" int spx_bn_relu_fwd(const float* x, int64_t n, const int64_t* d_n, int c, const float* gamma, const float* beta,
-                               float* running_mean, float* running_var, float momentum, float eps, int relu, float* y,
-                               float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, spx_stream_t stream) {
+extern "C" int spx_bn_add_relu_fwd(const float* x, const float* res, int64_t n, const int64_t* d_n, int c, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                   int relu, float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                                   spx_stream_t stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || n < 0 || c <= 0) return SPX_ERR_INVALID_ARG;
   if (c % 4 != 0 || 1024 % c != 0) return SPX_ERR_UNSUPPORTED;   // 4,8,16,...,1024
   if (!ws || ws_bytes < spx_bn_relu_ws_bytes(c)) return SPX_ERR_WORKSPACE;
@@ -206,18 +225,20 @@ extern "C" int spx_bn_relu_fwd(const float* x, int64_t n, const int64_t* d_n, in
   float* partial = reinterpret_cast<float*>(ws);
   int nb = bn_blocks(n, c);
   hipLaunchKernelGGL((k_bn_reduce<false>), dim3(nb), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, n, d_n, c, relu, partial);
+                     nullptr, n, d_n, c, relu, nullptr, partial);
   hipLaunchKernelGGL(k_bn_finalize, dim3(c), dim3(64), 0, s, partial, nb, c, n, d_n, eps, momentum, save_mean,
                      save_invstd, running_mean, running_var);
   if (n > 0)
-    hipLaunchKernelGGL(k_bn_apply, dim3(nb), dim3(256), 0, s, x, save_mean, save_invstd, gamma, beta, n, d_n, c, relu, y);
+    hipLaunchKernelGGL(k_bn_apply, dim3(nb), dim3(256), 0, s, x, save_mean, save_invstd, gamma, beta, n, d_n, c, relu, res,
+                       y);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }
 
-extern "C" int spx_bn_relu_bwd(const float* x, const float* dy, int64_t n, int c, const float* gamma, const float* beta,
-                               const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
-                               float* dbeta, void* ws, size_t ws_bytes, spx_stream_t stream) {
+extern "C" int spx_bn_add_relu_bwd(const float* x, const float* res, const float* dy, int64_t n, int c, const float* gamma,
+                                   const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
+                                   float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                   spx_stream_t stream) {
   if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || n <= 0 || c <= 0)
     return SPX_ERR_INVALID_ARG;
   if (c % 4 != 0 || 1024 % c != 0) return SPX_ERR_UNSUPPORTED;
@@ -226,10 +247,24 @@ extern "C" int spx_bn_relu_bwd(const float* x, const float* dy, int64_t n, int c
   float* partial = reinterpret_cast<float*>(ws);
   int nb = bn_blocks(n, c);
   hipLaunchKernelGGL((k_bn_reduce<true>), dim3(nb), dim3(256), 0, s, x, gamma, beta, dy, save_mean, save_invstd, n,
-                     nullptr, c, relu, partial);
+                     nullptr, c, relu, res, partial);
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(c), dim3(64), 0, s, partial, nb, c, dgamma, dbeta);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(nb), dim3(256), 0, s, x, beta, dy, save_mean, save_invstd, gamma, dgamma, dbeta,
-                     n, c, relu, dx);
+                     n, c, relu, res, dx, dres);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
+}
+
+extern "C" int spx_bn_relu_fwd(const float* x, int64_t n, const int64_t* d_n, int c, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, int relu, float* y,
+                               float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, spx_stream_t stream) {
+  return spx_bn_add_relu_fwd(x, nullptr, n, d_n, c, gamma, beta, running_mean, running_var, momentum, eps, relu, y, save_mean,
+                             save_invstd, ws, ws_bytes, stream);
+}
+
+extern "C" int spx_bn_relu_bwd(const float* x, const float* dy, int64_t n, int c, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
+                               float* dbeta, void* ws, size_t ws_bytes, spx_stream_t stream) {
+  return spx_bn_add_relu_bwd(x, nullptr, dy, n, c, gamma, beta, save_mean, save_invstd, relu, dx, nullptr, dgamma, dbeta, ws,
+                             ws_bytes, stream);
 }

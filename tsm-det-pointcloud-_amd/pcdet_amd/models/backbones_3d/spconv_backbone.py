@@ -10,6 +10,7 @@ from functools import partial
 import torch.nn as nn
 
 import spx as spconv
+from spx.functional import bn_act
 
 from ...utils.spconv_utils import replace_feature  # noqa: F401  (API parity)
 
@@ -52,9 +53,10 @@ class SparseBasicBlock(spconv.SparseModule):
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
         out = self.conv1(x)
-        out = out.replace_feature(self.relu(self.bn1(out.features)))
+        out = out.replace_feature(bn_act(out.features, self.bn1, True))
         out = self.conv2(out)
-        out = out.replace_feature(self.relu(self.bn2(out.features) + identity.features))
+        # bn2 + identity + ReLU: one fused kernel pair in training (spx_bn_add_relu_*), the torch modules otherwise
+        out = out.replace_feature(bn_act(out.features, self.bn2, True, identity.features))
         return out
 
 

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 import spx as spconv
+from spx.functional import bn_act
 
 from ...utils import common_utils
 from .spconv_backbone import post_act_block
@@ -41,9 +42,9 @@ class SparseBasicBlock(spconv.SparseModule):
         assert x.features.dim() == 2, 'x.features.dim()=%d' % x.features.dim()
         skip = x.features if self.downsample is None else self.downsample(x)
         y = self.conv1(x)
-        y = y.replace_feature(self.relu(self.bn1(y.features)))
+        y = y.replace_feature(bn_act(y.features, self.bn1, True))
         y = self.conv2(y)
-        return y.replace_feature(self.relu(self.bn2(y.features) + skip))
+        return y.replace_feature(bn_act(y.features, self.bn2, True, skip))          # bn2 + skip + ReLU, one kernel pair
 
 
 # encoder stages: (name, [(cin, cout, conv_type, indice_key, stride, padding), ...])

@@ -46,3 +46,39 @@ class VoxelQueryAndGrouping(nn.Module):
         grouped_xyz = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)
         grouped_features = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
         return grouped_features, grouped_xyz, empty_ball_mask, density
+
+
+def voxel_query_dilated(max_range, stride, former_radius, radius, nsample, xyz, new_xyz, new_coords, point_indices):
+    """-> idx, empty_ball_mask, density_score (M, 1) = min(occupied cells scanned / nsample, 1) (reference
+    VoxelQueryDilated.forward, voxel_query_utils.py:119-158; kernel voxel_query_gpu.cu:125-215)."""
+    idx, cnt, _filled = ops.voxel_query_dilated(new_xyz, xyz, new_coords, point_indices, nsample, former_radius, radius,
+                                                tuple(max_range), tuple(stride))
+    empty_ball_mask = idx[:, 0] == -1
+    idx[empty_ball_mask] = 0
+    density_score = torch.clamp(cnt.view(-1, 1) / nsample, max=1.0)
+    return idx, empty_ball_mask, density_score
+
+
+class VoxelQueryAndGroupingDilated(nn.Module):
+    """reference voxel_query_utils.py:168-236.  The reference turns global rows into frame-local ones with
+    `idx.view(batch_size, -1, nsample)`, i.e. it needs the same number of queries in every frame; the per-frame offsets
+    used here give the same result in that case and stay correct for ragged frames."""
+
+    def __init__(self, max_range, stride, former_radius, radius, nsample):
+        super().__init__()
+        self.max_range, self.stride, self.former_radius, self.radius, self.nsample = \
+            max_range, stride, former_radius, radius, nsample
+
+    def forward(self, new_coords, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, voxel2point_indices):
+        assert xyz.shape[0] == xyz_batch_cnt.sum() and new_coords.shape[0] == new_xyz_batch_cnt.sum()
+        idx, empty_ball_mask, density_score = voxel_query_dilated(
+            self.max_range, self.stride, self.former_radius, self.radius, self.nsample, xyz, new_xyz, new_coords,
+            voxel2point_indices)
+        offsets = torch.cumsum(xyz_batch_cnt, 0) - xyz_batch_cnt
+        frame_of_query = torch.repeat_interleave(torch.arange(new_xyz_batch_cnt.shape[0], device=idx.device),
+                                                 new_xyz_batch_cnt.long())
+        idx = idx - offsets[frame_of_query][:, None].to(idx.dtype)
+        idx[empty_ball_mask] = 0
+        grouped_xyz = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)
+        grouped_features = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
+        return grouped_features, grouped_xyz, empty_ball_mask, density_score

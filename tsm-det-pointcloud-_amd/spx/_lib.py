@@ -34,6 +34,8 @@ SIGNATURES = {
     "spx_dynamic_voxelize": (_int, [_vp, _i64, _int, _int, _int, _int, _f32p, _f32p, _i32p, _int, _vp, _vp, _vp, _vp, _i64,
                                     _vp, _sz, _vp]),
     "spx_voxel_query": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i32p, _int, ctypes.c_float, _i32p, _vp, _vp, _vp]),
+    "spx_voxel_query_dilated": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i32p, _int, ctypes.c_float, ctypes.c_float, _i32p,
+                                       _i32p, _vp, _vp, _vp, _vp]),
     "spx_mean_vfe": (_int, [_vp, _vp, _i64, _vp, _int, _int, _vp, _vp]),
     "spx_subm_rulebook_ws_bytes": (_sz, [_i64]),
     "spx_subm_rulebook": (_int, [_vp, _i64, _vp, _int, _i32p, _i32p, _i32p, _vp, _i64, _vp, _vp, _sz, _vp]),
@@ -60,6 +62,10 @@ SIGNATURES = {
     "spx_bn_relu_fwd": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _int, _vp, _vp,
                                _vp, _vp, _sz, _vp]),
     "spx_bn_relu_bwd": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "spx_bn_add_relu_fwd": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _int, _vp,
+                                   _vp, _vp, _vp, _sz, _vp]),
+    "spx_bn_add_relu_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz,
+                                   _vp]),
     "spx_anchor_loss_ws_bytes": (_sz, [_int, _i64]),
     "spx_anchor_loss": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _int, _int, ctypes.c_float, ctypes.c_float,
                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _sz,

@@ -115,26 +115,48 @@ def dense(feats, indices, batch_size, spatial_shape, channels_last=False, d_n=No
 
 
 class _BNReLUFn(torch.autograd.Function):
-    """Training-mode BatchNorm1d (+ReLU) on sparse feature rows: libspx kernels forward and backward."""
+    """Training-mode BatchNorm1d (+ residual) (+ReLU) on sparse feature rows: libspx kernels forward and backward."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
-        y, mean, invstd = ops.bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu)
-        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None):
+        y, mean, invstd = ops.bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual)
+        if residual is None:
+            ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        else:
+            ctx.save_for_backward(x, gamma, beta, mean, invstd, residual)
         ctx.relu = relu
         ctx.mark_non_differentiable(running_mean, running_var) if running_mean is not None else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, beta, mean, invstd = ctx.saved_tensors
-        dx, dgamma, dbeta = ops.bn_relu_bwd(x, dy, gamma, beta, mean, invstd, ctx.relu)
-        return dx, dgamma, dbeta, None, None, None, None, None
+        x, gamma, beta, mean, invstd = ctx.saved_tensors[:5]
+        residual = ctx.saved_tensors[5] if len(ctx.saved_tensors) > 5 else None
+        out = ops.bn_relu_bwd(x, dy, gamma, beta, mean, invstd, ctx.relu, residual)
+        return out[0], out[1], out[2], None, None, None, None, None, (out[3] if residual is not None else None)
 
 
-def bn_relu_train(x, bn, relu):
-    """x [N, C] through `bn` (nn.BatchNorm1d in training mode, affine, tracking running stats) and optionally ReLU."""
+def bn_train_fusable(bn, f):
+    """True when libspx's training-mode BatchNorm kernels cover `bn` applied to the rows of f [N, C]."""
+    return (isinstance(bn, torch.nn.BatchNorm1d) and bn.training and bn.affine and bn.track_running_stats and f.is_cuda
+            and f.dtype == torch.float32 and f.dim() == 2 and f.shape[0] > 1 and ops.bn_relu_supported(f.shape[1]))
+
+
+def bn_relu_train(x, bn, relu, residual=None):
+    """x [N, C] through `bn` (nn.BatchNorm1d in training mode, affine, tracking running stats), plus `residual` when
+    given, and optionally ReLU."""
     mom = bn.momentum if bn.momentum is not None else 0.1
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return _BNReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, relu)
+    return _BNReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, relu, residual)
+
+
+def bn_act(x, bn, relu, residual=None):
+    """relu(bn(x) + residual) on feature rows: the fused kernels when they apply (training on the GPU), else the torch
+    modules in the reference's order (spconv_backbone.py:56-72)."""
+    if bn_train_fusable(bn, x):
+        return bn_relu_train(x, bn, relu, residual)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return torch.relu(y) if relu else y

@@ -105,8 +105,7 @@ def _train_bn_tail(mods, i, x):
         return None
     bn = mods[i + 1]
     f = x.features
-    if not (isinstance(bn, nn.BatchNorm1d) and bn.training and bn.affine and bn.track_running_stats and f.is_cuda
-            and f.dtype == torch.float32 and f.shape[0] > 1 and ops.bn_relu_supported(f.shape[1])):
+    if not F_.bn_train_fusable(bn, f):
         return None
     relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
     return bn, relu, (3 if relu else 2)

@@ -423,41 +423,48 @@ def bn_relu_supported(c):
     return c % 4 == 0 and 1024 % c == 0
 
 
-def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu):
-    """Training-mode BatchNorm1d over the rows of x [N, C] (+ReLU).  Updates running_mean / running_var in place.
-    Returns y, save_mean, save_invstd."""
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None):
+    """Training-mode BatchNorm1d over the rows of x [N, C] (+ residual) (+ReLU).  Updates running_mean / running_var in
+    place.  Returns y, save_mean, save_invstd."""
     _need_gpu(x, gamma, beta)
     lib = _lib.load()
     x = x.contiguous()
     n, c = x.shape
+    if residual is not None:
+        residual = residual.contiguous()
+        if residual.shape != x.shape or residual.dtype != x.dtype or residual.device != x.device:
+            raise ValueError("residual must match x: %s vs %s" % (tuple(residual.shape), tuple(x.shape)))
     y = torch.empty_like(x)
     mean = torch.empty((c,), dtype=torch.float32, device=x.device)
     invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
     wsb = lib.spx_bn_relu_ws_bytes(c)
     ws = workspace(x.device, wsb)
-    check(lib.spx_bn_relu_fwd(_ptr(x), n, None, c, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                              float(momentum), float(eps), int(bool(relu)), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(ws),
-                              wsb, _stream(x)), "spx_bn_relu_fwd")
+    check(lib.spx_bn_add_relu_fwd(_ptr(x), _ptr(residual), n, None, c, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                  _ptr(running_var), float(momentum), float(eps), int(bool(relu)), _ptr(y), _ptr(mean),
+                                  _ptr(invstd), _ptr(ws), wsb, _stream(x)), "spx_bn_add_relu_fwd")
     return y, mean, invstd
 
 
-def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu):
-    """Backward of bn_relu_fwd; the ReLU mask is recomputed from x inside the kernels (y is not read)."""
+def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu, residual=None):
+    """Backward of bn_relu_fwd; the ReLU mask is recomputed from x (and the residual) inside the kernels (y is not
+    read).  Returns dx, dgamma, dbeta and, with a residual, dresidual."""
     _need_gpu(x, dy)
     lib = _lib.load()
     dy = dy.contiguous()
     n, c = x.shape
     dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if residual is not None else None
     dgamma = torch.empty((c,), dtype=torch.float32, device=x.device)
     dbeta = torch.empty((c,), dtype=torch.float32, device=x.device)
     if n == 0:
-        return dx, dgamma.zero_(), dbeta.zero_()
+        out = (dx, dgamma.zero_(), dbeta.zero_())
+        return out if residual is None else out + (dres,)
     wsb = lib.spx_bn_relu_ws_bytes(c)
     ws = workspace(x.device, wsb)
-    check(lib.spx_bn_relu_bwd(_ptr(x), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd),
-                              int(bool(relu)), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream(x)),
-          "spx_bn_relu_bwd")
-    return dx, dgamma, dbeta
+    check(lib.spx_bn_add_relu_bwd(_ptr(x), _ptr(residual), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(mean),
+                                  _ptr(invstd), int(bool(relu)), _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+                                  wsb, _stream(x)), "spx_bn_add_relu_bwd")
+    return (dx, dgamma, dbeta) if residual is None else (dx, dgamma, dbeta, dres)
 
 
 # ------------------------------------------------------------------------------------------- voxel query (row f-4)
@@ -476,3 +483,22 @@ def voxel_query(new_xyz, xyz, new_coords, point_indices, nsample, radius, ranges
                               int(nsample), float(radius), i3(ranges), _ptr(idx), _ptr(cnt), _stream(xyz)),
           "spx_voxel_query")
     return idx, cnt
+
+
+def voxel_query_dilated(new_xyz, xyz, new_coords, point_indices, nsample, former_radius, radius, ranges, strides):
+    """Raw kernel result of spx_voxel_query_dilated: idx [M, nsample] int32, cnt_unique [M] (occupied cells scanned) and
+    idx_cnt [M] (slots filled before padding)."""
+    _need_gpu(new_xyz, xyz, new_coords, point_indices)
+    lib = _lib.load()
+    new_xyz, xyz = new_xyz.contiguous().float(), xyz.contiguous().float()
+    new_coords, point_indices = new_coords.contiguous().int(), point_indices.contiguous().int()
+    m = new_coords.shape[0]
+    b, z, y, x = point_indices.shape
+    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
+    cnt = torch.zeros((m,), dtype=torch.int32, device=xyz.device)
+    filled = torch.zeros((m,), dtype=torch.int32, device=xyz.device)
+    check(lib.spx_voxel_query_dilated(_ptr(new_xyz), _ptr(xyz), _ptr(new_coords), _ptr(point_indices), m, b,
+                                      i3([z, y, x]), int(nsample), float(former_radius), float(radius), i3(ranges),
+                                      i3(strides), _ptr(idx), _ptr(cnt), _ptr(filled), _stream(xyz)),
+          "spx_voxel_query_dilated")
+    return idx, cnt, filled
