@@ -158,7 +158,7 @@ class KernelTimer(object):
     def install(self):
         from spx import ops
         t = self
-        names = ["conv_gemm", "conv_gemm_balanced", "conv_plan", "conv_wgrad", "subm_rulebook", "conv_rulebook", "voxelize",
+        names = ["conv_gemm", "conv_gemm_balanced", "conv_plan", "conv_group", "conv_wgrad", "subm_rulebook", "conv_rulebook", "voxelize",
                  "densify", "densify_bwd", "pack_weight"]
         self._saved = {n: getattr(ops, n) for n in names}
         sv = self._saved
@@ -175,16 +175,20 @@ class KernelTimer(object):
                             scale, shift, relu, d_n_dst)
 
         def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k=False, scale=None, shift=None,
-                               relu=False, d_n_dst=None):
+                               relu=False, d_n_dst=None, perm=None):
             P = t._P(pair, n_dst)
             cs = src.shape[1]
             flops = 2.0 * P * cs * c_dst
             nbytes = 4.0 * (src.shape[0] * cs + n_dst * c_dst + kvol * cs * c_dst + kvol * n_dst)
             return t._timed("conv_gemm[mfma %dx%d balanced]" % (cs, c_dst), flops, nbytes, sv["conv_gemm_balanced"], src, w_packed,
-                            c_dst, kvol, pair, ld, n_dst, plan, flip_k, scale, shift, relu, d_n_dst)
+                            c_dst, kvol, pair, ld, n_dst, plan, flip_k, scale, shift, relu, d_n_dst, perm)
 
         def conv_plan(pair, ld, kvol, n_dst, d_n_dst=None):
             return t._timed("conv_plan", 0.0, 4.0 * kvol * n_dst, sv["conv_plan"], pair, ld, kvol, n_dst, d_n_dst)
+
+        def conv_group(pair, ld, kvol, n_dst, d_n_dst=None):
+            # reads the table, writes perm and the grouped table
+            return t._timed("conv_group", 0.0, 4.0 * (2 * kvol + 1) * n_dst, sv["conv_group"], pair, ld, kvol, n_dst, d_n_dst)
 
         def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
             cout, cin = wshape[0], wshape[-1]
@@ -192,7 +196,9 @@ class KernelTimer(object):
             P = t._P(pair, n_out)
             flops = 2.0 * P * cin * cout
             nbytes = 4.0 * (feat_in.shape[0] * cin + n_out * cout + K * n_out + K * cin * cout)
-            return t._timed("conv_wgrad", flops, nbytes, sv["conv_wgrad"], feat_in, dout, pair, ld, n_out, wshape)
+            # one family per template instantiation (k_wgrad_mfma<cin/16, cout/16, ..>), like the forward kernels
+            return t._timed("conv_wgrad[mfma %dx%d]" % (cin, cout), flops, nbytes, sv["conv_wgrad"], feat_in, dout, pair, ld,
+                            n_out, wshape)
 
         def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None):
             n = indices.shape[0]
@@ -234,7 +240,7 @@ class KernelTimer(object):
             return t._timed("pack_weight", 0.0, 8.0 * weight.numel(), sv["pack_weight"], weight, mode)
 
         for n, f in dict(conv_gemm=conv_gemm, conv_gemm_balanced=conv_gemm_balanced, conv_plan=conv_plan,
-                         conv_wgrad=conv_wgrad, subm_rulebook=subm_rulebook,
+                         conv_group=conv_group, conv_wgrad=conv_wgrad, subm_rulebook=subm_rulebook,
                          conv_rulebook=conv_rulebook, voxelize=voxelize, densify=densify, densify_bwd=densify_bwd,
                          pack_weight=pack_weight).items():
             setattr(ops, n, f)
@@ -292,8 +298,12 @@ def roofline_of(fam):
     elif name.startswith("conv_gemm[mfma "):
         cs, cd = name[len("conv_gemm[mfma "):-1].split("x")
         rocprof_name = "k_conv_mfma<%s, %s," % (cs, cd)
-    elif name == "conv_wgrad":
-        rocprof_name = "k_wgrad_mfma"
+    elif name.startswith("conv_wgrad[mfma "):
+        def _t(c):   # template argument of k_wgrad_mfma for a channel count (csrc/conv_wgrad.hip: spx_conv_wgrad)
+            m = (int(c) + 15) // 16
+            return 4 if m == 3 else (8 if m > 4 else m)
+        ci, co = name[len("conv_wgrad[mfma "):-1].split("x")
+        rocprof_name = "k_wgrad_mfma<%d, %d," % (_t(ci), _t(co))       # one API call = + k_wgrad_count + k_wgrad_reduce
     traffic = pmc_traffic(rocprof_name)
     if traffic is not None and extra_name is not None:
         traffic += pmc_traffic(extra_name) or 0.0

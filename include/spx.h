@@ -179,14 +179,24 @@ int spx_conv_gemm(const float *src, int c_src, const float *w_packed, int c_dst,
  * depends only on (pair, n_dst), so it is reused by every convolution that reads the table (forward, dgrad with
  * flip_k, the second layer of a submanifold pair).  spx_conv_gemm_balanced = spx_conv_gemm under that schedule;
  * returns SPX_ERR_UNSUPPORTED for channel pairs it does not cover (use spx_conv_gemm).  Same reference call sites. */
+/* Optional row order for that schedule (csrc/conv_group.hip): a 16-row MFMA tile multiplies offset k for all its rows
+ * as soon as one of them has it, so tiles whose rows share the same offsets issue fewer wasted MFMAs.  spx_conv_group
+ * sorts the destination rows of a rule table by their offset mask (stable) and writes perm[n_dst] (position -> table row)
+ * and pair_grouped[kvol][n_dst] = pair[k][perm[j]] (-1 beyond the live rows).  Build the plan over pair_grouped (ld =
+ * n_dst) and pass pair_grouped + perm to spx_conv_gemm_balanced: position j is written to dst row perm[j].  Results do
+ * not depend on the row order (every row is the same sum over k).  kvol <= 30. */
+size_t spx_conv_group_ws_bytes(int64_t n_dst);
+int spx_conv_group(const int32_t *pair, int64_t pair_ld, int kvol, int64_t n_dst, const int64_t *d_n_dst, int32_t *perm,
+                   int32_t *pair_grouped, void *ws, size_t ws_bytes, spx_stream_t stream);
+/* perm (below): NULL = rows in table order */
 size_t spx_conv_plan_bytes(int64_t n_dst);
 int spx_conv_plan(const int32_t *pair, int64_t pair_ld, int kvol, int64_t n_dst, const int64_t *d_n_dst, int32_t *plan,
                   spx_stream_t stream);
 size_t spx_conv_gemm_balanced_ws_bytes(int c_dst, int64_t n_dst);
 int spx_conv_gemm_balanced(const float *src, int c_src, const float *w_packed, int c_dst, int kvol, int flip_k,
                            const int32_t *pair, int64_t pair_ld, int64_t n_dst, const int64_t *d_n_dst,
-                           const float *scale, const float *shift, int relu, const int32_t *plan, float *dst, void *ws,
-                           size_t ws_bytes, spx_stream_t stream);
+                           const float *scale, const float *shift, int relu, const int32_t *plan, const int32_t *perm,
+                           float *dst, void *ws, size_t ws_bytes, spx_stream_t stream);
 
 size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n_out);
 int spx_conv_wgrad(const float *in, int cin, const float *dout, int cout, int kvol, const int32_t *pair,

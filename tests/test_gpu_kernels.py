@@ -336,6 +336,45 @@ def test_conv_balanced_schedule_matches_tile_per_wave(orc):
         assert _rel_t(out, ref) < 2e-6 and float(out.min()) >= 0.0
 
 
+@pytest.mark.parametrize("frames,n_live", [(4, None), (1, None), (2, 9000)])
+def test_conv_grouped_row_order(frames, n_live, orc):
+    """spx_conv_group: perm is the stable sort of the rows by offset mask (a permutation; dead rows last), the grouped
+    table is the table read through perm, the plan over it holds fewer (super-tile, offset) units, and the balanced
+    conv over the grouped rows returns the rows of the ungrouped result (same per-row sums) — forward, flipped, with
+    the fused epilogue, and with a device-side live-row count."""
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, 2, frames)
+    dev = _dev()
+    d_idx = torch.from_numpy(idx_np).to(dev)
+    g = torch.Generator().manual_seed(23)
+    d_n = None if n_live is None else torch.tensor([n_live], dtype=torch.int64, device=dev)
+    sub = ops.subm_rulebook(d_idx, frames, shape, (3, 3, 3), d_n=d_n)
+    n, K = sub.n_out, 27
+    live = n if n_live is None else n_live
+    perm, grouped = ops.conv_group(sub.pair, sub.ld, K, n, d_n)
+    pair = sub.pair[:, :n]
+    mask = ((pair >= 0).to(torch.int64) << torch.arange(K, device=dev)[:, None]).sum(0)
+    key = torch.where(torch.arange(n, device=dev) < live, mask, torch.full_like(mask, 1 << 30))
+    assert torch.equal(perm.long(), torch.argsort(key, stable=True))
+    want = pair[:, perm.long()].clone()
+    want[:, live:] = -1
+    assert torch.equal(grouped, want)
+    plan_c = ops.conv_plan(sub.pair, sub.ld, K, n, d_n)
+    plan_g = ops.conv_plan(grouped, n, K, n, d_n)
+    assert int(plan_g[1]) < int(plan_c[1])                              # fewer MFMA units to issue
+    for cs, cd in ((64, 64), (32, 32)):
+        w = (torch.randn(cd, 3, 3, 3, cs, generator=g) / np.sqrt(27 * cs)).to(dev)
+        wp = ops.pack_weight(w, 0)
+        x = torch.randn(n, cs, generator=g).to(dev)
+        sc, sh = (torch.rand(cd, generator=g) + 0.5).to(dev), torch.randn(cd, generator=g).to(dev)
+        for flip, kw in ((False, {}), (True, {}), (False, dict(scale=sc, shift=sh, relu=True))):
+            ref = ops.conv_gemm(x, wp, cd, K, sub.pair, sub.ld, n, flip_k=flip, d_n_dst=d_n, **kw)
+            out = ops.conv_gemm_balanced(x, wp, cd, K, grouped, n, n, plan_g, flip_k=flip, d_n_dst=d_n, perm=perm, **kw)
+            assert _rel_t(out[:live], ref[:live]) < 2e-6
+            again = ops.conv_gemm_balanced(x, wp, cd, K, grouped, n, n, plan_g, flip_k=flip, d_n_dst=d_n, perm=perm, **kw)
+            assert torch.equal(out[:live], again[:live])
+
+
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 200, 1000, 5000])
 def test_conv_balanced_small_and_ragged_sizes(n):
     """The balanced schedule at sizes where most workgroups have nothing to do, rows do not fill the last 16-row tile /

@@ -33,6 +33,25 @@ def backbone8x_layers(input_channels=4):
     return rows
 
 
+def grouped(pair, ld, K, n, window, flip=False):
+    """perm (processing position -> table row), rows ordered by (window, offset mask), and the table in that order.
+    window == -2: libspx's own spx_conv_group (one window), checked against the torch construction."""
+    if window == -2:
+        from spx import ops
+        perm, pp = ops.conv_group(pair, ld, K, n)
+        perm_t, pp_t = grouped(pair, ld, K, n, -1)
+        assert torch.equal(perm, perm_t) and torch.equal(pp, pp_t), "spx_conv_group differs from the torch construction"
+        t = timeit(lambda: ops.conv_group(pair, ld, K, n), 20)
+        print("    spx_conv_group n=%d: %.1f us" % (n, t * 1e6))
+        return perm, pp
+    has = pair[:K, :n] >= 0
+    w = (1 << torch.arange(K, device=pair.device, dtype=torch.int64))[:, None]
+    mask = (has.to(torch.int64) * w).sum(0)
+    win = torch.arange(n, device=pair.device, dtype=torch.int64) // (window if window > 0 else n)
+    perm = torch.argsort((win << 27) | mask, stable=True).to(torch.int32)
+    return perm, pair[:K, :n][:, perm.long()].contiguous()
+
+
 def timeit(fn, iters):
     for _ in range(3):
         fn()
@@ -54,6 +73,9 @@ def main():
     ap.add_argument("--what", default="fwd,dgrad,wgrad,rulebook")
     ap.add_argument("--layers", default="")
     ap.add_argument("--balanced", action="store_true", help="fwd/dgrad through the balanced persistent schedule")
+    ap.add_argument("--group", type=int, default=0,
+                    help="with --balanced: also time the schedule over rows grouped by offset mask inside windows of this "
+                         "many rows (-1: one window)")
     args = ap.parse_args()
     what = args.what.split(",")
     dev = torch.device("cuda:0")
@@ -110,6 +132,13 @@ def main():
             if bal_f:
                 plan = ops.conv_plan(rb.pair, rb.ld, K, rb.n_out)
                 t = timeit(lambda: ops.conv_gemm_balanced(x, wp, cout, K, rb.pair, rb.ld, rb.n_out, plan), args.iters)
+                if args.group:
+                    perm, pp = grouped(rb.pair, rb.ld, K, rb.n_out, args.group)
+                    plang = ops.conv_plan(pp, rb.n_out, K, rb.n_out)
+                    fg = (lambda: ops.conv_gemm_balanced(x, wp, cout, K, pp, rb.n_out, rb.n_out, plang, perm=perm))
+                    err = float((fg() - ops.conv_gemm_balanced(x, wp, cout, K, rb.pair, rb.ld, rb.n_out, plan)).abs().max())
+                    tg = timeit(fg, args.iters)
+                    line += " | fwd grouped %7.1f us (units %d -> %d, err %.1e)" % (tg * 1e6, int(plan[1]), int(plang[1]), err)
             else:
                 t = timeit(lambda: ops.conv_gemm(x, wp, cout, K, rb.pair, rb.ld, rb.n_out), args.iters)
             tot["fwd"] += t
@@ -120,6 +149,13 @@ def main():
                 tb, ldb = (rb.pair, rb.ld) if rb.subm else (rb.pair_bwd, rb.pair_bwd.shape[1])
                 planb = ops.conv_plan(tb, ldb, K, rb.n_in)
                 f = (lambda: ops.conv_gemm_balanced(dout, wt, cin, K, tb, ldb, rb.n_in, planb, flip_k=rb.subm))
+                if args.group:
+                    permb, ppb = grouped(tb, ldb, K, rb.n_in, args.group)
+                    plangb = ops.conv_plan(ppb, rb.n_in, K, rb.n_in)
+                    fgb = (lambda: ops.conv_gemm_balanced(dout, wt, cin, K, ppb, rb.n_in, rb.n_in, plangb, flip_k=rb.subm,
+                                                          perm=permb))
+                    errb = float((fgb() - f()).abs().max())
+                    line += " | dgrad grouped %7.1f us (err %.1e)" % (timeit(fgb, args.iters) * 1e6, errb)
             elif rb.subm:
                 f = (lambda: ops.conv_gemm(dout, wt, cin, K, rb.pair, rb.ld, rb.n_in, flip_k=True))
             else:

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
                                                        int64_t n, const int64_t* d_n, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu,
                                                        const int32_t* __restrict__ plan, int64_t t4cap,
-                                                       float* __restrict__ dst, float* __restrict__ scratch) {
+                                                       const int32_t* __restrict__ perm, float* __restrict__ dst,
+                                                       float* __restrict__ scratch) {
   constexpr int NT = CD / 16;
   constexpr int JG = CS / 16;
   constexpr int NF = NT * JG;               // 1 KiB weight fragments per offset
@@ -300,6 +301,12 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
       // last owned offset of super-tile c0.S: write this wave's 16 rows.  C layout: col = lane&15, row = 4*(lane>>4) + e
       const int64_t row_base = (int64_t)c0.S * kRows + 16 * wave;
       if (c0.whole) {
+        int64_t drow[4];                       // where the rows of this position go: perm[] under a grouped row order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int64_t orow = row_base + 4 * q + e;
+          drow[e] = orow < nlive ? (perm ? (int64_t)perm[orow] : orow) : -1;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int col = 16 * nt + r;
@@ -307,12 +314,11 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
           const float sh = shift ? shift[col] : 0.0f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int64_t orow = row_base + 4 * q + e;
-            if (orow < nlive) {
+            if (drow[e] >= 0) {
               float v = acc[nt][e];
               if (scale || shift) v = v * sc + sh;
               if (relu) v = v > 0.f ? v : 0.f;
-              dst[orow * CD + col] = v;
+              dst[drow[e] * CD + col] = v;
             }
           }
         }
@@ -360,6 +366,7 @@ template <int CD>
 __global__ __launch_bounds__(256) void k_conv_fixup(const int32_t* __restrict__ plan, int64_t t4cap, int64_t n,
                                                     const int64_t* d_n, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, int relu,
+                                                    const int32_t* __restrict__ perm,
                                                     const float* __restrict__ scratch, float* __restrict__ dst) {
   constexpr int V = kRows * CD / 4;                    // float4 pieces per super-tile
   const int nb = plan[0], U = plan[1], T4 = plan[2];
@@ -403,7 +410,8 @@ __global__ __launch_bounds__(256) void k_conv_fixup(const int32_t* __restrict__ 
       if (relu) x = x > 0.f ? x : 0.f;
       v[e] = x;
     }
-    *reinterpret_cast<f32x4*>(dst + orow * CD + c0) = v;
+    const int64_t drow = perm ? (int64_t)perm[orow] : orow;
+    *reinterpret_cast<f32x4*>(dst + drow * CD + c0) = v;
   }
 }
 
@@ -412,15 +420,15 @@ static inline int64_t tiles4_cap(int64_t n) { return (n + kRows - 1) / kRows + 1
 template <int CS, int CD>
 static void launch_pb(const float* src, const float* wp, const int32_t* pair, int64_t ld, int K, int flip, int64_t n,
                       const int64_t* d_n, const float* scale, const float* shift, int relu, const int32_t* plan,
-                      float* dst, float* scratch, hipStream_t s) {
+                      const int32_t* perm, float* dst, float* scratch, hipStream_t s) {
   const int64_t t4cap = tiles4_cap(n);
   constexpr int kStatic = 2 * (CS / 16) * (CD / 16) * 1024;      // the two weight buffers
   // (a 16-wave workgroup fills a CU's wave slots at this register count by itself: no padding needed)
   const int pad = (kWpb == 4 && kLdsPerBlock > kStatic) ? kLdsPerBlock - kStatic : 0;
   hipLaunchKernelGGL((k_conv_mfma_pbl<CS, CD>), dim3(kBlocks), dim3(64 * kWpb), pad, s, src, wp, pair, ld, K, flip, n, d_n, scale,
-                     shift, relu, plan, t4cap, dst, scratch);
+                     shift, relu, plan, t4cap, perm, dst, scratch);
   hipLaunchKernelGGL((k_conv_fixup<CD>), dim3((unsigned)((n + kRows - 1) / kRows)), dim3(256), 0, s, plan, t4cap, n, d_n, scale, shift,
-                     relu, scratch, dst);
+                     relu, perm, scratch, dst);
 }
 
 }  // namespace
@@ -449,16 +457,16 @@ extern "C" size_t spx_conv_gemm_balanced_ws_bytes(int c_dst, int64_t n_dst) {
 
 #define SPX_PB_CASE(A, B)                                                                                            \
   if (c_src == A && c_dst == B) {                                                                                    \
-    launch_pb<A, B>(src, w_packed, pair, pair_ld, kvol, flip_k, n_dst, d_n_dst, scale, shift, relu, plan, dst, scratch, \
-                    s);                                                                                              \
+    launch_pb<A, B>(src, w_packed, pair, pair_ld, kvol, flip_k, n_dst, d_n_dst, scale, shift, relu, plan, perm, dst,    \
+                    scratch, s);                                                                                        \
     SPX_CHECK_LAUNCH();                                                                                              \
     return SPX_OK;                                                                                                   \
   }
 
 extern "C" int spx_conv_gemm_balanced(const float* src, int c_src, const float* w_packed, int c_dst, int kvol, int flip_k,
                                       const int32_t* pair, int64_t pair_ld, int64_t n_dst, const int64_t* d_n_dst,
-                                      const float* scale, const float* shift, int relu, const int32_t* plan, float* dst,
-                                      void* ws, size_t ws_bytes, spx_stream_t stream) {
+                                      const float* scale, const float* shift, int relu, const int32_t* plan,
+                                      const int32_t* perm, float* dst, void* ws, size_t ws_bytes, spx_stream_t stream) {
   if (!src || !w_packed || !pair || !dst || !plan || c_src <= 0 || c_dst <= 0 || kvol <= 0 || kvol > SPX_MAX_KVOL ||
       n_dst <= 0 || pair_ld < n_dst)
     return SPX_ERR_INVALID_ARG;

@@ -48,8 +48,10 @@ SIGNATURES = {
     "spx_conv_plan_bytes": (_sz, [_i64]),
     "spx_conv_plan": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp]),
     "spx_conv_gemm_balanced_ws_bytes": (_sz, [_int, _i64]),
+    "spx_conv_group_ws_bytes": (_sz, [_i64]),
+    "spx_conv_group": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spx_conv_gemm_balanced": (_int, [_vp, _int, _vp, _int, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp,
-                                      _sz, _vp]),
+                                      _vp, _sz, _vp]),
     "spx_conv_wgrad_ws_bytes": (_sz, [_int, _int, _int, _i64]),
     "spx_conv_wgrad": (_int, [_vp, _int, _vp, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "spx_densify": (_int, [_vp, _vp, _i64, _vp, _int, _int, _i32p, _int, _vp, _vp]),

@@ -31,10 +31,15 @@ def _packed(weight, mode):
 
 
 def _conv(src, wp, c_dst, kvol, pair, ld, n_dst, flip, scale, shift, relu, d_n, rb):
-    """One gather-GEMM launch: the MFMA-work-balanced persistent schedule where it applies (plan cached on the rulebook),
-    the one-tile-per-wave kernel otherwise."""
+    """One gather-GEMM launch: the MFMA-work-balanced persistent schedule where it applies (plan cached on the rulebook;
+    over rows grouped by offset mask for submanifold tables, which several launches share), the one-tile-per-wave
+    kernel otherwise."""
     if (rb is not None and src.is_cuda and n_dst > 0 and src.shape[0] > 0
             and ops.balanced_ok(src.shape[1], c_dst, n_dst)):
+        if ops.grouped_ok(rb, kvol):
+            perm, grouped, plan = ops.grouped_plan_for(rb, pair, ld, kvol, n_dst, d_n)
+            return ops.conv_gemm_balanced(src, wp, c_dst, kvol, grouped, n_dst, n_dst, plan, flip_k=flip, scale=scale,
+                                          shift=shift, relu=relu, d_n_dst=d_n, perm=perm)
         plan = ops.plan_for(rb, pair, ld, kvol, n_dst, d_n)
         return ops.conv_gemm_balanced(src, wp, c_dst, kvol, pair, ld, n_dst, plan, flip_k=flip, scale=scale, shift=shift,
                                       relu=relu, d_n_dst=d_n)

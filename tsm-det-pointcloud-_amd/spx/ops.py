@@ -239,9 +239,12 @@ def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=N
 
 
 _BALANCED_SHAPES = {(64, 64)}   # measured: 32x32 slower, 32x64 / 64x32 even (plan cost included)
+if os.environ.get("SPX_CONV_BALANCED_SHAPES"):   # dev knob: "32x32,32x64,64x32,64x64"
+    _BALANCED_SHAPES = {tuple(int(v) for v in t.split("x")) for t in os.environ["SPX_CONV_BALANCED_SHAPES"].split(",")}
 # below this many destination rows the plan / fix-up launches cost more than the balanced schedule saves
 _BALANCED_MIN_ROWS = int(os.environ.get("SPX_CONV_BALANCED_MIN_ROWS", "24000"))
 _BALANCED = os.environ.get("SPX_CONV_BALANCED", "1") != "0"
+_GROUPED = os.environ.get("SPX_CONV_GROUPED", "1") != "0"       # dev knob: rows grouped by offset mask (csrc/conv_group.hip)
 
 
 def conv_plan(pair, ld, kvol, n_dst, d_n_dst=None):
@@ -253,6 +256,30 @@ def conv_plan(pair, ld, kvol, n_dst, d_n_dst=None):
     return plan
 
 
+def conv_group(pair, ld, kvol, n_dst, d_n_dst=None):
+    """Rows of a rule table grouped by offset mask (include/spx.h: spx_conv_group) -> perm [n_dst] int32 and the table
+    in that order [kvol, n_dst] int32."""
+    _need_gpu(pair)
+    lib = _lib.load()
+    perm = torch.empty((n_dst,), dtype=torch.int32, device=pair.device)
+    grouped = torch.empty((kvol, n_dst), dtype=torch.int32, device=pair.device)
+    wsb = lib.spx_conv_group_ws_bytes(n_dst)
+    ws = workspace(pair.device, wsb)
+    check(lib.spx_conv_group(_ptr(pair), ld, kvol, n_dst, _ptr(d_n_dst), _ptr(perm), _ptr(grouped), _ptr(ws), wsb,
+                             _stream(pair)), "spx_conv_group")
+    return perm, grouped
+
+
+def grouped_plan_for(rb, pair, ld, kvol, n_dst, d_n_dst=None):
+    """(perm, grouped table, plan over it) of rule table `pair`, built once per Rulebook and table."""
+    key = ("g", pair.data_ptr(), int(n_dst))
+    hit = rb._plans.get(key)
+    if hit is None:
+        perm, grouped = conv_group(pair, ld, kvol, n_dst, d_n_dst)
+        hit = rb._plans[key] = (perm, grouped, conv_plan(grouped, n_dst, kvol, n_dst, d_n_dst))
+    return hit
+
+
 def plan_for(rb, pair, ld, kvol, n_dst, d_n_dst=None):
     """Plan of rule table `pair`, built once per Rulebook and table (forward, dgrad and sibling layers share it)."""
     key = (pair.data_ptr(), int(n_dst))
@@ -262,12 +289,18 @@ def plan_for(rb, pair, ld, kvol, n_dst, d_n_dst=None):
     return plan
 
 
+def grouped_ok(rb, kvol):
+    """Grouping the rows costs one sort per rule table: worth it for submanifold tables (forward and dgrad of two
+    layers read the same one), not for the single-use tables of strided convolutions."""
+    return _GROUPED and rb.subm and kvol <= 30
+
+
 def balanced_ok(c_src, c_dst, n_dst):
     return _BALANCED and (c_src, c_dst) in _BALANCED_SHAPES and n_dst >= _BALANCED_MIN_ROWS
 
 
 def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k=False, scale=None, shift=None,
-                       relu=False, d_n_dst=None):
+                       relu=False, d_n_dst=None, perm=None):
     """conv_gemm under the MFMA-work-balanced persistent schedule (`plan` from conv_plan on the same table / n_dst)."""
     _need_gpu(src, w_packed, pair, plan)
     lib = _lib.load()
@@ -278,7 +311,7 @@ def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k
     ws = workspace(src.device, wsb)
     check(lib.spx_conv_gemm_balanced(_ptr(src), src.shape[1], _ptr(w_packed), c_dst, kvol, int(bool(flip_k)), _ptr(pair),
                                      ld, n_dst, _ptr(d_n_dst), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(plan),
-                                     _ptr(dst), _ptr(ws), wsb, _stream(src)), "spx_conv_gemm_balanced")
+                                     _ptr(perm), _ptr(dst), _ptr(ws), wsb, _stream(src)), "spx_conv_gemm_balanced")
     return dst
 
 
