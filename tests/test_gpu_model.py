@@ -506,6 +506,54 @@ def test_bev_block_rewrites_match_plain_sequential():
         assert _rel(p.float(), q.float()) < 1e-5, n
 
 
+@pytest.mark.parametrize("stride,channels_last", [(1, True), (2, True), (1, False)])
+def test_bev_sparse_entry_matches_dense_conv(stride, channels_last):
+    """BaseBEVBackbone's first convolution run over the active rows of the encoded sparse tensor (sparse conv with kernel
+    (D,3,3) + densify) against the dense ZeroPad2d + Conv2d on HeightCompression's map (reference
+    base_bev_backbone.py:27-34 on height_compression.py:21-23): output everywhere, gradient of the Conv2d weight and of
+    the encoded features.  fp32, 1e-5 relative (the dense kernel adds exact zeros in between, in another order)."""
+    import torch.nn as nn
+    import spx
+    from pcdet_amd.config import AttrDict
+    from pcdet_amd.models.backbones_2d import base_bev_backbone as bb
+    from pcdet_amd.models.backbones_2d.map_to_bev import HeightCompression
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    B, D, H, W, C, CO = 2, 2, 100, 88, 64, 128
+    occ = torch.rand(B, D, H, W, generator=g) < 0.08
+    idx = occ.nonzero().int().to(dev)                                           # (b, z, y, x), batch-major sorted
+    feats = torch.randn(idx.shape[0], C, generator=g).to(dev)
+    seq = nn.Sequential(nn.ZeroPad2d(1), nn.Conv2d(C * D, CO, 3, stride=stride, padding=0, bias=False),
+                        nn.BatchNorm2d(CO, eps=1e-3, momentum=0.01), nn.ReLU()).to(dev).train()
+    if channels_last:
+        seq = seq.to(memory_format=torch.channels_last)
+    hc = HeightCompression(AttrDict(NUM_BEV_FEATURES=C * D, CHANNELS_LAST=channels_last))
+
+    def run(sparse):
+        seq.zero_grad()
+        f = feats.clone().requires_grad_(True)
+        enc = spx.SparseConvTensor(f, idx, [D, H, W], B)
+        bev = hc({'encoded_spconv_tensor': enc, 'encoded_spconv_tensor_stride': 8})['spatial_features']
+        assert bev.is_contiguous(memory_format=torch.channels_last) == channels_last or not channels_last
+        y = bb._sparse_entry(seq, bev) if sparse else bb._run_block(nn.Sequential(*list(seq)[:2]), bev)
+        assert y is not None
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+        (y * gy).sum().backward()
+        return y.detach(), f.grad.clone(), seq[1].weight.grad.clone()
+
+    ys, gfs, gws = run(True)
+    yd, gfd, gwd = run(False)
+    assert ys.shape == yd.shape and ys.is_contiguous(memory_format=torch.channels_last) == yd.is_contiguous(
+        memory_format=torch.channels_last)
+    assert _rel(ys, yd) < 1e-5 and _rel(gfs, gfd) < 1e-5 and _rel(gws, gwd) < 1e-5
+    # a map that is not HeightCompression's own output (here: a copy) takes the dense route
+    enc = spx.SparseConvTensor(feats, idx, [D, H, W], B)
+    bev = hc({'encoded_spconv_tensor': enc, 'encoded_spconv_tensor_stride': 8})['spatial_features']
+    assert bb._sparse_entry(seq, bev.clone()) is None
+    bev.add_(1.0)                                       # written to after HeightCompression: the tag is stale
+    assert bb._sparse_entry(seq, bev) is None
+
+
 def test_fused_head_convs_match_separate_convs():
     """AnchorHeadSingle._heads (one conv over the concatenated filters; a GEMM under no_grad) against the three
     separate 1x1 convs of the reference formulation, values and gradients."""
