@@ -294,13 +294,19 @@ int spx_bn_relu_bwd(const float *x, const float *dy, int64_t n, int c, const flo
 
 /* y = relu(bn(x) + res): the tail of SparseBasicBlock (reference spconv_backbone.py:56-72: bn2, `out.features +
  * identity.features`, ReLU; SURVEY.md §8 row f-3 "fused residual add epilogue").  res [n, c] or NULL (= spx_bn_relu_*);
- * backward also writes dres [n, c] (may be NULL) = dy masked by the ReLU, the gradient of the identity branch. */
+ * backward also writes dres [n, c] (may be NULL) = dy masked by the ReLU, the gradient of the identity branch.
+ * num_batches_tracked: nn.BatchNorm's int64 counter, incremented by one inside the kernels (NULL: not touched).
+ * y_ld / dy_ld: row stride in floats of y / dy (0 = c): a layer can write its output straight into a channel slice of a
+ * wider [n, y_ld] matrix (the channel concatenation of the BEV up-sampling branches, reference
+ * base_bev_backbone.py:99-106) and read its gradient from the same slice; multiples of 4, 16-byte aligned base. */
 int spx_bn_add_relu_fwd(const float *x, const float *res, int64_t n, const int64_t *d_n, int c, const float *gamma,
-                        const float *beta, float *running_mean, float *running_var, float momentum, float eps, int relu,
-                        float *y, float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, spx_stream_t stream);
-int spx_bn_add_relu_bwd(const float *x, const float *res, const float *dy, int64_t n, int c, const float *gamma,
-                        const float *beta, const float *save_mean, const float *save_invstd, int relu, float *dx,
-                        float *dres, float *dgamma, float *dbeta, void *ws, size_t ws_bytes, spx_stream_t stream);
+                        const float *beta, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                        float momentum, float eps, int relu, float *y, int64_t y_ld, float *save_mean, float *save_invstd,
+                        void *ws, size_t ws_bytes, spx_stream_t stream);
+int spx_bn_add_relu_bwd(const float *x, const float *res, const float *dy, int64_t dy_ld, int64_t n, int c,
+                        const float *gamma, const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                        float *dx, float *dres, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
+                        spx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 10. Voxel query (consumers of multi_scale_3d_features)

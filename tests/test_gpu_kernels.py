@@ -728,3 +728,50 @@ def test_fused_bn_add_relu_train_matches_torch(n, c, relu):
     mine.eval()
     with torch.no_grad():
         assert torch.equal(F_.bn_act(x, mine, relu, res), torch.relu(mine(x) + res) if relu else mine(x) + res)
+
+
+def test_fused_bn_relu_cat_matches_torch():
+    """bn_relu_cat_train (BN+ReLU of several branches written into the channel slices of one matrix, gradients read from
+    the slices in place; the BEV up-sampling concatenation, reference base_bev_backbone.py:99-106) against
+    torch.cat([relu(bn_i(x_i))], 1) with nn.BatchNorm1d: output, all gradients, running statistics, counters."""
+    import copy
+    from spx import functional as F_
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    n, widths = 30011, (256, 128, 64)
+    xs = [(torch.randn(n, c, generator=g) * 1.7 + 0.3).to(dev) for c in widths]
+    refs = [torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev).train() for c in widths]
+    with torch.no_grad():
+        for r in refs:
+            r.weight.copy_(torch.rand(r.num_features, generator=g) + 0.5)
+            r.bias.copy_(torch.randn(r.num_features, generator=g) * 0.2)
+        for _ in range(3):          # keep pre-activations away from 0 so that both sides take the same ReLU branch
+            for r, x in zip(refs, xs):
+                z = copy.deepcopy(r)(x)
+                x[z.abs() < 1e-3] += 0.02
+        assert min(float(copy.deepcopy(r)(x).abs().min()) for r, x in zip(refs, xs)) > 1e-5
+    mine = copy.deepcopy(refs)
+    dy = torch.randn(n, sum(widths), generator=g).to(dev)
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    yr = torch.cat([torch.relu(r(x)) for r, x in zip(refs, xr)], 1)
+    yr.backward(dy)
+    xm = [x.clone().requires_grad_(True) for x in xs]
+    ym = F_.bn_relu_cat_train(xm, mine)
+    assert ym.shape == yr.shape and ym.is_contiguous()
+    ym.backward(dy)
+    _close(ym.detach().cpu().numpy(), yr.detach().cpu().numpy(), tol=2e-5)
+    for a, b, m, r in zip(xm, xr, mine, refs):
+        _close(a.grad.cpu().numpy(), b.grad.cpu().numpy(), tol=5e-5)
+        _close(m.weight.grad.cpu().numpy(), r.weight.grad.cpu().numpy(), tol=5e-5)
+        _close(m.bias.grad.cpu().numpy(), r.bias.grad.cpu().numpy(), tol=5e-5)
+        _close(m.running_mean.cpu().numpy(), r.running_mean.cpu().numpy(), tol=1e-6)
+        _close(m.running_var.cpu().numpy(), r.running_var.cpu().numpy(), tol=1e-6)
+        assert int(m.num_batches_tracked) == int(r.num_batches_tracked) == 1
+    # a gradient that arrives as a non-contiguous view takes the copy route and gives the same numbers
+    xm2 = [x.clone().requires_grad_(True) for x in xs]
+    ym2 = F_.bn_relu_cat_train(xm2, copy.deepcopy(refs))
+    wide = torch.zeros(n, sum(widths) + 3, device=dev)
+    wide[:, 3:] = dy
+    ym2.backward(wide[:, 3:])
+    for a, b in zip(xm2, xm):
+        assert torch.equal(a.grad, b.grad)

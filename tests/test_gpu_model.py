@@ -554,6 +554,56 @@ def test_bev_sparse_entry_matches_dense_conv(stride, channels_last):
     assert bb._sparse_entry(seq, bev) is None
 
 
+def test_bev_backbone_fused_paths_match_plain_modules():
+    """BaseBEVBackbone.forward with everything it fuses on the GPU (sparse entry conv, fused BN2d+ReLU, BN+ReLU written
+    into the channel slices of the concatenated map) against the same modules applied one by one the way the reference
+    does (base_bev_backbone.py:81-112): spatial_features_2d, the gradient of the encoded features and of every
+    parameter, running statistics and counters."""
+    import spx
+    from pcdet_amd.config import AttrDict
+    from pcdet_amd.models.backbones_2d import base_bev_backbone as bb
+    from pcdet_amd.models.backbones_2d.map_to_bev import HeightCompression
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    B, D, H, W, C = 2, 2, 96, 88, 64
+    cfg = AttrDict(LAYER_NUMS=[1, 1], LAYER_STRIDES=[1, 2], NUM_FILTERS=[64, 128], UPSAMPLE_STRIDES=[1, 2],
+                   NUM_UPSAMPLE_FILTERS=[128, 128])
+    net = bb.BaseBEVBackbone(cfg, C * D).to(dev).to(memory_format=torch.channels_last).train()
+    ref = copy.deepcopy(net)
+    occ = torch.rand(B, D, H, W, generator=g) < 0.1
+    idx = occ.nonzero().int().to(dev)
+    feats = torch.randn(idx.shape[0], C, generator=g).to(dev)
+    hc = HeightCompression(AttrDict(NUM_BEV_FEATURES=C * D, CHANNELS_LAST=True))
+    gy = torch.randn(B, 256, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+
+    def run(model, fused):
+        f = feats.clone().requires_grad_(True)
+        d = hc({'encoded_spconv_tensor': spx.SparseConvTensor(f, idx, [D, H, W], B), 'encoded_spconv_tensor_stride': 8})
+        if fused:
+            out = model(d)['spatial_features_2d']
+        else:
+            x, ups = d['spatial_features'].clone(), []                    # the copy drops the sparse-entry tag
+            for blk, deb in zip(model.blocks, model.deblocks):
+                x = blk(x)
+                ups.append(deb(x))
+            out = torch.cat(ups, 1)
+        (out * gy).sum().backward()
+        return out.detach(), f.grad
+
+    old = bb._FUSED_BN_MIN_ELEMS
+    bb._FUSED_BN_MIN_ELEMS = 0
+    try:
+        ya, ga = run(net, True)
+    finally:
+        bb._FUSED_BN_MIN_ELEMS = old
+    yb, gb = run(ref, False)
+    assert ya.shape == yb.shape and _rel(ya, yb) < 2e-5 and _rel(ga, gb) < 1e-4
+    for (n_, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert _rel(p.grad, q.grad) < 1e-4, n_
+    for (n_, p), (_, q) in zip(net.named_buffers(), ref.named_buffers()):
+        assert _rel(p.float(), q.float()) < 1e-5, n_
+
+
 def test_fused_head_convs_match_separate_convs():
     """AnchorHeadSingle._heads (one conv over the concatenated filters; a GEMM under no_grad) against the three
     separate 1x1 convs of the reference formulation, values and gradients."""

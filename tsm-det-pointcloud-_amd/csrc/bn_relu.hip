@@ -44,13 +44,19 @@ __device__ __forceinline__ f32x4 bn_out(f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f
   return o;
 }
 
+// element offset of float4 piece i of a [N][C] matrix stored with row stride ld (C is a power of two: C | 1024)
+__device__ __forceinline__ int64_t strided4(int64_t i, int C, int cshift, int64_t ld) {
+  const int64_t e = i * 4;
+  return (e >> cshift) * ld + (e & (C - 1));
+}
+
 // grid-stride over float4 elements of x[N][C]; because 256*4 % C == 0 is NOT assumed, each thread recomputes its channel
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ x, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ dy,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    int64_t n, const int64_t* d_n, int C, int relu,
-                                                   const float* __restrict__ res,
+                                                   const float* __restrict__ res, int64_t dy_ld, int cshift,
                                                    float* __restrict__ partial /*[grid][2][C]*/) {
   __shared__ float sm[256][8];   // per-thread partials (4 channels x {a, b})
   const int64_t nlive = spx_live_n(d_n, n);
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ x, 
       a += v;
       b += v * v;
     } else {
-      f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+      f32x4 g = *reinterpret_cast<const f32x4*>(dy + strided4(i, C, cshift, dy_ld));
       if (relu) {
         const f32x4 o = bn_out(v, mu, is, ga, be, res, i);
 #pragma unroll
@@ -117,7 +123,7 @@ __device__ __forceinline__ void wave_sum2(double& s, double& q) {
 __global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ partial, int nblk, int C, int64_t n,
                                                     const int64_t* d_n, float eps, float momentum, float* __restrict__ mean,
                                                     float* __restrict__ invstd, float* __restrict__ running_mean,
-                                                    float* __restrict__ running_var) {
+                                                    float* __restrict__ running_var, int64_t* __restrict__ nbt) {
   const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 64) {
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ pa
   }
   wave_sum2(s, q);
   if (threadIdx.x != 0) return;
+  if (nbt && c == 0) *nbt += 1;              // nn.BatchNorm's num_batches_tracked, without a launch of its own
   const double N = (double)spx_live_n(d_n, n);
   double m = N > 0 ? s / N : 0.0;
   double var = N > 0 ? q / N - m * m : 0.0;
@@ -142,7 +149,8 @@ __global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ pa
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean,
                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, int64_t n, const int64_t* d_n, int C,
-                                                  int relu, const float* __restrict__ res, float* __restrict__ y) {
+                                                  int relu, const float* __restrict__ res, int64_t y_ld, int cshift,
+                                                  float* __restrict__ y) {
   const int64_t total4 = spx_live_n(d_n, n) * C / 4;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
     }
-    reinterpret_cast<f32x4*>(y)[i] = o;
+    *reinterpret_cast<f32x4*>(y + strided4(i, C, cshift, y_ld)) = o;
   }
 }
 
@@ -179,14 +187,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                       int64_t n, int C, int relu, const float* __restrict__ res,
-                                                      float* __restrict__ dx, float* __restrict__ dres) {
+                                                      int64_t dy_ld, int cshift, float* __restrict__ dx,
+                                                      float* __restrict__ dres) {
   const int64_t total4 = n * C / 4;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const float invN = 1.0f / (float)n;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
     const int c0 = (int)((i * 4) % C);
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + strided4(i, C, cshift, dy_ld));
     f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
     f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
     if (relu) {
@@ -214,43 +223,55 @@ static inline int bn_blocks(int64_t n, int C) {
 
 extern "C" size_t spx_bn_relu_ws_bytes(int c) { return spx_align((size_t)kMaxBlocks * 2 * c * 4); }
 
+static inline int log2_of(int c) {
+  int sft = 0;
+  while ((1 << sft) < c) ++sft;
+  return sft;
+}
+
 extern "C" int spx_bn_add_relu_fwd(const float* x, const float* res, int64_t n, const int64_t* d_n, int c, const float* gamma,
-                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                   int relu, float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
-                                   spx_stream_t stream) {
+                                   const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                   float momentum, float eps, int relu, float* y, int64_t y_ld, float* save_mean,
+                                   float* save_invstd, void* ws, size_t ws_bytes, spx_stream_t stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || n < 0 || c <= 0) return SPX_ERR_INVALID_ARG;
   if (c % 4 != 0 || 1024 % c != 0) return SPX_ERR_UNSUPPORTED;   // 4,8,16,...,1024
+  if (y_ld == 0) y_ld = c;
+  if (y_ld < c || y_ld % 4 != 0 || ((uintptr_t)y & 15) != 0) return SPX_ERR_INVALID_ARG;
   if (!ws || ws_bytes < spx_bn_relu_ws_bytes(c)) return SPX_ERR_WORKSPACE;
   hipStream_t s = spx_s(stream);
   float* partial = reinterpret_cast<float*>(ws);
   int nb = bn_blocks(n, c);
+  const int cshift = log2_of(c);
   hipLaunchKernelGGL((k_bn_reduce<false>), dim3(nb), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, n, d_n, c, relu, nullptr, partial);
+                     nullptr, n, d_n, c, relu, nullptr, (int64_t)c, cshift, partial);
   hipLaunchKernelGGL(k_bn_finalize, dim3(c), dim3(64), 0, s, partial, nb, c, n, d_n, eps, momentum, save_mean,
-                     save_invstd, running_mean, running_var);
+                     save_invstd, running_mean, running_var, num_batches_tracked);
   if (n > 0)
     hipLaunchKernelGGL(k_bn_apply, dim3(nb), dim3(256), 0, s, x, save_mean, save_invstd, gamma, beta, n, d_n, c, relu, res,
-                       y);
+                       y_ld, cshift, y);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }
 
-extern "C" int spx_bn_add_relu_bwd(const float* x, const float* res, const float* dy, int64_t n, int c, const float* gamma,
-                                   const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
-                                   float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+extern "C" int spx_bn_add_relu_bwd(const float* x, const float* res, const float* dy, int64_t dy_ld, int64_t n, int c,
+                                   const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                                   int relu, float* dx, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                    spx_stream_t stream) {
   if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || n <= 0 || c <= 0)
     return SPX_ERR_INVALID_ARG;
   if (c % 4 != 0 || 1024 % c != 0) return SPX_ERR_UNSUPPORTED;
+  if (dy_ld == 0) dy_ld = c;
+  if (dy_ld < c || dy_ld % 4 != 0 || ((uintptr_t)dy & 15) != 0) return SPX_ERR_INVALID_ARG;
   if (!ws || ws_bytes < spx_bn_relu_ws_bytes(c)) return SPX_ERR_WORKSPACE;
   hipStream_t s = spx_s(stream);
   float* partial = reinterpret_cast<float*>(ws);
   int nb = bn_blocks(n, c);
+  const int cshift = log2_of(c);
   hipLaunchKernelGGL((k_bn_reduce<true>), dim3(nb), dim3(256), 0, s, x, gamma, beta, dy, save_mean, save_invstd, n,
-                     nullptr, c, relu, res, partial);
+                     nullptr, c, relu, res, dy_ld, cshift, partial);
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(c), dim3(64), 0, s, partial, nb, c, dgamma, dbeta);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(nb), dim3(256), 0, s, x, beta, dy, save_mean, save_invstd, gamma, dgamma, dbeta,
-                     n, c, relu, res, dx, dres);
+                     n, c, relu, res, dy_ld, cshift, dx, dres);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }
@@ -258,13 +279,13 @@ extern "C" int spx_bn_add_relu_bwd(const float* x, const float* res, const float
 extern "C" int spx_bn_relu_fwd(const float* x, int64_t n, const int64_t* d_n, int c, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, int relu, float* y,
                                float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, spx_stream_t stream) {
-  return spx_bn_add_relu_fwd(x, nullptr, n, d_n, c, gamma, beta, running_mean, running_var, momentum, eps, relu, y, save_mean,
-                             save_invstd, ws, ws_bytes, stream);
+  return spx_bn_add_relu_fwd(x, nullptr, n, d_n, c, gamma, beta, running_mean, running_var, nullptr, momentum, eps, relu, y,
+                             c, save_mean, save_invstd, ws, ws_bytes, stream);
 }
 
 extern "C" int spx_bn_relu_bwd(const float* x, const float* dy, int64_t n, int c, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
                                float* dbeta, void* ws, size_t ws_bytes, spx_stream_t stream) {
-  return spx_bn_add_relu_bwd(x, nullptr, dy, n, c, gamma, beta, save_mean, save_invstd, relu, dx, nullptr, dgamma, dbeta, ws,
+  return spx_bn_add_relu_bwd(x, nullptr, dy, c, n, c, gamma, beta, save_mean, save_invstd, relu, dx, nullptr, dgamma, dbeta, ws,
                              ws_bytes, stream);
 }

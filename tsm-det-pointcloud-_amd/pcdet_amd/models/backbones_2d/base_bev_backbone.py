@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from spx import ops
-from spx.functional import bn_relu_train, dense as densify_rows, sparse_conv
+from spx.functional import bn_relu_cat_train, bn_relu_train, dense as densify_rows, sparse_conv
 
 # below this many activations the three-launch fused BN kernel is launch-bound and MIOpen's BN is faster (measured on
 # MI355X, tools/dense_tail_probe.py: 18 M elements 176 -> 132 us fwd+bwd, 9 M elements 98 -> 123 us)
@@ -49,6 +49,7 @@ def _run_block(seq, x, start=0):
 
 
 _SPARSE_ENTRY = os.environ.get("SPX_BEV_SPARSE_ENTRY", "1") != "0"     # dev knob
+_FUSED_CAT = os.environ.get("SPX_BEV_FUSED_CAT", "1") != "0"            # dev knob
 _SPARSE_ENTRY_CHANNELS = (16, 32, 64, 128)                                # MFMA instantiations of libspx's conv kernels
 
 
@@ -137,16 +138,43 @@ class BaseBEVBackbone(nn.Module):
         self.num_voxel_neck_features = c_in            # read by the fork's build_backbone_2d
         self.num_point_features = kwargs.get('num_point_features', None)
 
+    def _cat_fusable(self):
+        """The up-sampling branches end in training-mode BatchNorm2d + ReLU and are concatenated right after: their
+        BN+ReLU kernels can write into the channel slices of the concatenated map (no torch.cat copy forward, no slice
+        copies backward)."""
+        if not _FUSED_CAT or len(self.deblocks) != len(self.blocks) or len(self.deblocks) < 2:
+            return False
+        for d in self.deblocks:
+            mods = list(d)
+            if not (len(mods) == 3 and isinstance(mods[1], nn.BatchNorm2d) and isinstance(mods[2], nn.ReLU)
+                    and mods[1].training and mods[1].affine and mods[1].track_running_stats
+                    and 1024 % mods[1].num_features == 0 and mods[1].num_features % 4 == 0):
+                return False
+        return True
+
     def forward(self, data_dict):
         spatial_features = data_dict['spatial_features']
-        ups = []
+        ups, pre = [], []
         x = spatial_features
+        fuse_cat = self._cat_fusable() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
         for i in range(len(self.blocks)):
             y = _sparse_entry(self.blocks[i], x) if i == 0 else None
             x = _run_block(self.blocks[i], x) if y is None else _run_block(self.blocks[i], y, start=2)
             stride = int(spatial_features.shape[2] / x.shape[2])
             data_dict['spatial_features_%dx' % stride] = x
-            ups.append(_run_block(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
+            if fuse_cat:
+                pre.append(self.deblocks[i][0](x))                      # the up-sampling conv; BN + ReLU follow below
+            else:
+                ups.append(_run_block(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
+        if fuse_cat:
+            b, _c, h, w = pre[0].shape
+            if all(t.shape[0] == b and t.shape[2:] == pre[0].shape[2:] and t.numel() >= _FUSED_BN_MIN_ELEMS
+                   and t.is_contiguous(memory_format=torch.channels_last) for t in pre):
+                rows = [t.permute(0, 2, 3, 1).reshape(b * h * w, t.shape[1]) for t in pre]
+                y = bn_relu_cat_train(rows, [d[1] for d in self.deblocks])
+                ups = [y.view(b, h, w, y.shape[1]).permute(0, 3, 1, 2)]
+            else:
+                ups = [_run_block(d, t, start=1) for d, t in zip(self.deblocks, pre)]
         if len(ups) > 1:
             x = torch.cat(ups, dim=1)
         elif len(ups) == 1:

@@ -123,8 +123,9 @@ class _BNReLUFn(torch.autograd.Function):
     """Training-mode BatchNorm1d (+ residual) (+ReLU) on sparse feature rows: libspx kernels forward and backward."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None):
-        y, mean, invstd = ops.bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual)
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None, nbt=None):
+        y, mean, invstd = ops.bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual,
+                                          num_batches_tracked=nbt)
         if residual is None:
             ctx.save_for_backward(x, gamma, beta, mean, invstd)
         else:
@@ -138,7 +139,57 @@ class _BNReLUFn(torch.autograd.Function):
         x, gamma, beta, mean, invstd = ctx.saved_tensors[:5]
         residual = ctx.saved_tensors[5] if len(ctx.saved_tensors) > 5 else None
         out = ops.bn_relu_bwd(x, dy, gamma, beta, mean, invstd, ctx.relu, residual)
-        return out[0], out[1], out[2], None, None, None, None, None, (out[3] if residual is not None else None)
+        return out[0], out[1], out[2], None, None, None, None, None, (out[3] if residual is not None else None), None
+
+
+class _BNReLUCatFn(torch.autograd.Function):
+    """relu(bn_i(x_i)) for several row matrices x_i [N, C_i] written side by side into ONE [N, sum C_i] matrix: the
+    channel concatenation of the BEV up-sampling branches (reference base_bev_backbone.py:99-106: deblocks, then
+    torch.cat(ups, dim=1)) without the concatenation copy, and backward without the slice copies (each layer reads its
+    gradient from its channel slice in place)."""
+
+    @staticmethod
+    def forward(ctx, momenta, epss, *args):
+        k = len(momenta)
+        xs, gammas, betas = args[:k], args[k:2 * k], args[2 * k:3 * k]
+        rms, rvs, nbts = args[3 * k:4 * k], args[4 * k:5 * k], args[5 * k:6 * k]
+        n = xs[0].shape[0]
+        widths = [x.shape[1] for x in xs]
+        out = torch.empty((n, sum(widths)), dtype=torch.float32, device=xs[0].device)
+        saved, off = [], 0
+        for i in range(k):
+            _y, mean, invstd = ops.bn_relu_fwd(xs[i], gammas[i], betas[i], rms[i], rvs[i], momenta[i], epss[i], True,
+                                               out=out[:, off:off + widths[i]], num_batches_tracked=nbts[i])
+            saved += [xs[i].contiguous(), gammas[i], betas[i], mean, invstd]
+            off += widths[i]
+        ctx.save_for_backward(*saved)
+        ctx.widths = widths
+        ctx.mark_non_differentiable(*[t for t in rms + rvs + nbts if t is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k = len(ctx.widths)
+        s = ctx.saved_tensors
+        if dout.stride(1) != 1 or dout.stride(0) % 4 != 0 or dout.data_ptr() % 16 != 0:
+            dout = dout.contiguous()
+        dxs, dgs, dbs, off = [], [], [], 0
+        for i in range(k):
+            x, gamma, beta, mean, invstd = s[5 * i:5 * i + 5]
+            dx, dg, db = ops.bn_relu_bwd(x, dout[:, off:off + ctx.widths[i]], gamma, beta, mean, invstd, True)
+            dxs.append(dx), dgs.append(dg), dbs.append(db)
+            off += ctx.widths[i]
+        return (None, None) + tuple(dxs) + tuple(dgs) + tuple(dbs) + (None,) * (3 * k)
+
+
+def bn_relu_cat_train(xs, bns):
+    """[relu(bn_i(x_i))] concatenated along the channel axis -> [N, sum C_i]; bns: nn.BatchNorm modules in training mode
+    that libspx's kernels cover (see bn_train_fusable for the conditions on each pair)."""
+    moms = tuple(bn.momentum if bn.momentum is not None else 0.1 for bn in bns)
+    epss = tuple(bn.eps for bn in bns)
+    args = (tuple(xs) + tuple(bn.weight for bn in bns) + tuple(bn.bias for bn in bns) + tuple(bn.running_mean for bn in bns)
+            + tuple(bn.running_var for bn in bns) + tuple(bn.num_batches_tracked for bn in bns))
+    return _BNReLUCatFn.apply(moms, epss, *args)
 
 
 def bn_train_fusable(bn, f):
@@ -151,9 +202,9 @@ def bn_relu_train(x, bn, relu, residual=None):
     """x [N, C] through `bn` (nn.BatchNorm1d in training mode, affine, tracking running stats), plus `residual` when
     given, and optionally ReLU."""
     mom = bn.momentum if bn.momentum is not None else 0.1
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return _BNReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, relu, residual)
+    # num_batches_tracked is incremented inside the finalize kernel (one launch less per layer)
+    return _BNReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, relu, residual,
+                           bn.num_batches_tracked)
 
 
 def bn_act(x, bn, relu, residual=None):

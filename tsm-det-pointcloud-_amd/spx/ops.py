@@ -456,9 +456,17 @@ def bn_relu_supported(c):
     return c % 4 == 0 and 1024 % c == 0
 
 
-def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None):
-    """Training-mode BatchNorm1d over the rows of x [N, C] (+ residual) (+ReLU).  Updates running_mean / running_var in
-    place.  Returns y, save_mean, save_invstd."""
+def _row_view_ok(t, n, c):
+    """[n, c] float32 view whose rows are contiguous and 16-byte aligned at a row stride that is a multiple of 4."""
+    return (t.dim() == 2 and tuple(t.shape) == (n, c) and t.dtype == torch.float32 and (n <= 1 or t.stride(0) % 4 == 0)
+            and (c == 1 or t.stride(1) == 1) and t.stride(0) >= c and t.data_ptr() % 16 == 0)
+
+
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None, out=None,
+                num_batches_tracked=None):
+    """Training-mode BatchNorm1d over the rows of x [N, C] (+ residual) (+ReLU).  Updates running_mean / running_var
+    (and num_batches_tracked, when given) in place.  `out`: optional [N, C] view with its own row stride (a channel
+    slice of a wider matrix) that receives y.  Returns y, save_mean, save_invstd."""
     _need_gpu(x, gamma, beta)
     lib = _lib.load()
     x = x.contiguous()
@@ -467,24 +475,34 @@ def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, 
         residual = residual.contiguous()
         if residual.shape != x.shape or residual.dtype != x.dtype or residual.device != x.device:
             raise ValueError("residual must match x: %s vs %s" % (tuple(residual.shape), tuple(x.shape)))
-    y = torch.empty_like(x)
+    if out is None:
+        y = torch.empty_like(x)
+    else:
+        if not (_row_view_ok(out, n, c) and out.device == x.device):
+            raise ValueError("out must be a float32 [N, C] row view (row stride a multiple of 4, 16-byte aligned)")
+        y = out
+    y_ld = y.stride(0) if n > 1 else c
     mean = torch.empty((c,), dtype=torch.float32, device=x.device)
     invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
     wsb = lib.spx_bn_relu_ws_bytes(c)
     ws = workspace(x.device, wsb)
     check(lib.spx_bn_add_relu_fwd(_ptr(x), _ptr(residual), n, None, c, _ptr(gamma), _ptr(beta), _ptr(running_mean),
-                                  _ptr(running_var), float(momentum), float(eps), int(bool(relu)), _ptr(y), _ptr(mean),
-                                  _ptr(invstd), _ptr(ws), wsb, _stream(x)), "spx_bn_add_relu_fwd")
+                                  _ptr(running_var), _ptr(num_batches_tracked), float(momentum), float(eps),
+                                  int(bool(relu)), _ptr(y), y_ld, _ptr(mean), _ptr(invstd), _ptr(ws), wsb, _stream(x)),
+          "spx_bn_add_relu_fwd")
     return y, mean, invstd
 
 
 def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu, residual=None):
     """Backward of bn_relu_fwd; the ReLU mask is recomputed from x (and the residual) inside the kernels (y is not
-    read).  Returns dx, dgamma, dbeta and, with a residual, dresidual."""
+    read).  dy may be a row view with its own stride (a channel slice of a wider gradient).  Returns dx, dgamma, dbeta
+    and, with a residual, dresidual."""
     _need_gpu(x, dy)
     lib = _lib.load()
-    dy = dy.contiguous()
     n, c = x.shape
+    if not _row_view_ok(dy, n, c):
+        dy = dy.contiguous()
+    dy_ld = dy.stride(0) if n > 1 else c
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if residual is not None else None
     dgamma = torch.empty((c,), dtype=torch.float32, device=x.device)
@@ -494,7 +512,7 @@ def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu, residual=None):
         return out if residual is None else out + (dres,)
     wsb = lib.spx_bn_relu_ws_bytes(c)
     ws = workspace(x.device, wsb)
-    check(lib.spx_bn_add_relu_bwd(_ptr(x), _ptr(residual), _ptr(dy), n, c, _ptr(gamma), _ptr(beta), _ptr(mean),
+    check(lib.spx_bn_add_relu_bwd(_ptr(x), _ptr(residual), _ptr(dy), dy_ld, n, c, _ptr(gamma), _ptr(beta), _ptr(mean),
                                   _ptr(invstd), int(bool(relu)), _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
                                   wsb, _stream(x)), "spx_bn_add_relu_bwd")
     return (dx, dgamma, dbeta) if residual is None else (dx, dgamma, dbeta, dres)
