@@ -78,18 +78,24 @@ def _sparse_entry(seq, bev):
     kh, kw = conv.kernel_size
     if not (feats.is_cuda and feats.dtype == torch.float32 and bev.dtype == torch.float32
             and not torch.is_autocast_enabled() and conv.in_channels == c * d and d * kh * kw <= 30
-            and c in _SPARSE_ENTRY_CHANNELS and conv.out_channels in _SPARSE_ENTRY_CHANNELS and feats.shape[0] > 0
-            and src.n_valid is None and not torch.cuda.is_current_stream_capturing()):
+            and c in _SPARSE_ENTRY_CHANNELS and conv.out_channels in _SPARSE_ENTRY_CHANNELS and feats.shape[0] > 0):
         return None
     p, s = int(pad.padding[0]), int(conv.stride[0])
-    rb = ops.conv_rulebook(src.indices, src.batch_size, src.spatial_shape, (d, kh, kw), (1, s, s), (0, p, p))
+    if src.n_valid is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                  # exact-size tables need a host sync
+        rb = ops.conv_rulebook(src.indices, src.batch_size, src.spatial_shape, (d, kh, kw), (1, s, s), (0, p, p))
+    else:
+        # static-capacity tensors (hipGraph inference): rows at capacity, live counts stay on the device, no sync
+        rb = ops.conv_rulebook(src.indices, src.batch_size, src.spatial_shape, (d, kh, kw), (1, s, s), (0, p, p),
+                               d_n_in=src.n_valid, cap=(src.static_caps or {}).get('bev_entry', None), sync=False)
     if rb.n_out == 0:
         return None
     # Conv2d weight [Co, c*D + z, ky, kx] -> sparse layout [Co, z, ky, kx, c]; a view, so the gradient lands in conv.weight
     w3 = conv.weight.view(conv.out_channels, c, d, kh, kw).permute(0, 2, 3, 4, 1)
     rows = sparse_conv(feats, w3, None, rb)
     channels_last = bev.is_contiguous(memory_format=torch.channels_last)
-    out = densify_rows(rows, rb.out_indices, src.batch_size, rb.out_shape, channels_last)     # [B, Co, 1, Ho, Wo]
+    out = densify_rows(rows, rb.out_indices, src.batch_size, rb.out_shape, channels_last, rb.d_n_out)   # [B, Co, 1, Ho, Wo]
     return out.view(out.shape[0], out.shape[1], out.shape[3], out.shape[4])
 
 

@@ -16,10 +16,9 @@ class HeightCompression(nn.Module):
         dense = encoded.dense(channels_last_memory=self.channels_last)
         n, c, d, h, w = dense.shape
         bev = dense.view(n, c * d, h, w)                               # BEV channel = c * D + z
-        if encoded.n_valid is None:
-            # where this map came from: lets BaseBEVBackbone run its first convolution over the active rows only
-            # (the map is zero everywhere else); a tensor derived from `bev` does not carry the tag
-            bev._spx_source = (encoded, bev._version)
+        # where this map came from: lets BaseBEVBackbone run its first convolution over the active rows only (the map
+        # is zero everywhere else); a tensor derived from `bev` does not carry the tag
+        bev._spx_source = (encoded, bev._version)
         batch_dict['spatial_features'] = bev
         batch_dict['spatial_features_stride'] = batch_dict['encoded_spconv_tensor_stride']
         return batch_dict
