@@ -113,6 +113,34 @@ def main():
         w = torch.cat([h.weight for h in heads], 0)
         bench("C heads fused conv 72  fwd", lambda: F.conv2d(xs, w))
         bench("C heads fused linear   fwd", lambda: F.linear(xs.permute(0, 2, 3, 1), w.view(72, 512)))
+    w72 = torch.cat([h.weight for h in heads], 0).detach()
+    b72 = torch.cat([h.bias for h in heads], 0).detach()
+    xd = xs.detach()
+
+    def lin_fwd_conv_bwd():
+        y = F.linear(xd.permute(0, 2, 3, 1), w72.view(72, 512), b72)
+        return torch.ops.aten.convolution_backward(gcat, xd, w72, [72], [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                   [True, True, True]), y
+
+    def lin_fwd_mixed_bwd():
+        y = F.linear(xd.permute(0, 2, 3, 1), w72.view(72, 512), b72)
+        g2 = gcat.permute(0, 2, 3, 1).reshape(-1, 72)
+        dx = g2 @ w72.view(72, 512)
+        rest = torch.ops.aten.convolution_backward(gcat, xd, w72, [72], [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                   [False, True, True])
+        return dx, rest, y
+
+    def lin_fwd_mixed_bwd2():
+        y = F.linear(xd.permute(0, 2, 3, 1), w72.view(72, 512), b72)
+        g2 = gcat.permute(0, 2, 3, 1).reshape(-1, 72)
+        dw = g2.t() @ xd.permute(0, 2, 3, 1).reshape(-1, 512)
+        rest = torch.ops.aten.convolution_backward(gcat, xd, w72, [72], [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                   [True, False, True])
+        return dw, rest, y
+
+    bench("C heads linear fwd + conv bwd (dx, dw, db)", lin_fwd_conv_bwd)
+    bench("C heads linear fwd + mm dx + conv (dw, db)", lin_fwd_mixed_bwd)
+    bench("C heads linear fwd + mm dw + conv (dx, db)", lin_fwd_mixed_bwd2)
     bench("C heads 3 separate 1x1 fwd+bwd", sep)
     bench("C heads fused conv 72  fwd+bwd", fused)
     bench("C heads fused linear   fwd+bwd", fused_mm)

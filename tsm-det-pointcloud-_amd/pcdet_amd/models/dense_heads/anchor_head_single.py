@@ -1,11 +1,39 @@
 """AnchorHeadSingle (reference pcdet/models/dense_heads/anchor_head_single.py:8-88): three 1x1 convs (class, box,
 direction) + anchor decode.  Reads `encoded_bev_features` (list, the fork's key) or `spatial_features_2d`."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .anchor_head_template import AnchorHeadTemplate
+
+
+_HYBRID = os.environ.get("SPX_HEAD_HYBRID", "1") != "0"      # dev knob
+
+
+class _PointwiseHeadsFn(torch.autograd.Function):
+    """1x1 convolution of a channels_last map as the three GEMM-shaped pieces that are fastest on MI355X for a 512 -> 72
+    head (tools/dense_tail_probe.py, 4 x 200 x 176 pixels): forward = one GEMM over pixels (155 us; MIOpen's conv 267),
+    input gradient = one GEMM (dy @ W), weight / bias gradient = MIOpen's conv backward-weights (which reduces over the
+    141 k pixels better than a GEMM with that K).  fwd+bwd 489 us against 666 for conv2d's own backward.  Same dot
+    products as the three 1x1 convs of reference anchor_head_single.py:54-68."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.linear(x.permute(0, 2, 3, 1), w.flatten(1), b)           # [N, H, W, Co]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, h, wd, co = dy.shape
+        dx = (dy.view(-1, co) @ w.flatten(1)).view(n, h, wd, x.shape[1]).permute(0, 3, 1, 2)
+        _, dw, db = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), x, w, [co], [1, 1], [0, 0], [1, 1], False,
+                                                        [0, 0], 1, [False, True, True])
+        return dx, dw, db
 
 
 class AnchorHeadSingle(AnchorHeadTemplate):
@@ -37,10 +65,13 @@ class AnchorHeadSingle(AnchorHeadTemplate):
         convs = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
         w = torch.cat([c.weight for c in convs], 0)
         b = torch.cat([c.bias for c in convs], 0)
-        if not torch.is_grad_enabled() and x.is_contiguous(memory_format=torch.channels_last):
+        if (not x.is_contiguous(memory_format=torch.channels_last) or torch.is_autocast_enabled()
+                or (torch.is_grad_enabled() and not _HYBRID)):
+            y = F.conv2d(x, w, b).permute(0, 2, 3, 1)
+        elif not torch.is_grad_enabled():
             y = F.linear(x.permute(0, 2, 3, 1), w.flatten(1), b)          # inference: a plain GEMM over pixels
         else:
-            y = F.conv2d(x, w, b).permute(0, 2, 3, 1)
+            y = _PointwiseHeadsFn.apply(x, w, b)
         outs = [t.contiguous() for t in torch.split(y, [c.out_channels for c in convs], dim=3)]
         return outs[0], outs[1], (outs[2] if len(outs) > 2 else None)
 
