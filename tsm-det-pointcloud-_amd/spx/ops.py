@@ -14,8 +14,20 @@ from ._lib import check, f_arr, i3
 _WS = {}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the stream handle without building a Stream object
+
+
+def _stream_handle(device):
+    """torch's current stream on `device` as an integer handle (several microseconds cheaper per call than
+    torch.cuda.current_stream(): the small layers at the end of the backward pass are host bound)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(_stream_handle(t.device))
 
 
 def _ptr(t):
@@ -31,7 +43,7 @@ def _need_gpu(*ts):
 
 def workspace(device, nbytes):
     """Grow-only scratch buffer per (device, stream); stream order makes back-to-back reuse safe."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream_handle(device))
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
