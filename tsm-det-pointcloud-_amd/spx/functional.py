@@ -74,19 +74,64 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.fused:
             raise RuntimeError("fused scale/shift/relu epilogue is inference-only")
         feats, weight = ctx.saved_tensors
-        pair_f, ld_f, n_dst, pair_b, ld_b, flip_b = ctx.tables
+        dfe, dw, db = _conv_backward(feats, weight, ctx.tables, ctx.rb, ctx.d_n_src, ctx.has_bias, dout,
+                                     ctx.needs_input_grad[:3])
+        return dfe, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
+
+
+def _conv_backward(feats, weight, tables, rb, d_n_src, has_bias, dout, needs):
+    """dgrad (the same gather-GEMM with transposed weights over the backward table), wgrad, bias gradient."""
+    pair_f, ld_f, n_dst, pair_b, ld_b, flip_b = tables
+    cout, cin = weight.shape[0], weight.shape[-1]
+    kvol = weight.numel() // (cout * cin)
+    dout = dout.contiguous()
+    dfe = dw = db = None
+    if needs[0]:
+        wt = ops.pack_weight(weight, 1)
+        dfe = _conv(dout, wt, cin, kvol, pair_b, ld_b, feats.shape[0], flip_b, None, None, False, d_n_src, rb)
+    if needs[1]:
+        dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape))
+    if has_bias and needs[2]:
+        db = dout.sum(0)
+    return dfe, dw, db
+
+
+class _SparseConvBNReLUFn(torch.autograd.Function):
+    """Sparse conv + training-mode BatchNorm1d + ReLU of one `post_act_block` (reference spconv_backbone.py:9-35) as ONE
+    autograd node: the same kernels as _SparseConvFn followed by _BNReLUFn, half the python / autograd bookkeeping per
+    layer — the low-channel layers at the end of the backward pass are bound by that bookkeeping, not by their kernels
+    (tools/host_overhead.py)."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias, gamma, beta, running_mean, running_var, nbt, momentum, eps, relu, tables, rb,
+                d_n, d_n_src):
+        pair_f, ld_f, n_dst = tables[:3]
         cout, cin = weight.shape[0], weight.shape[-1]
         kvol = weight.numel() // (cout * cin)
-        dout = dout.contiguous()
-        dfe = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt = ops.pack_weight(weight, 1)
-            dfe = _conv(dout, wt, cin, kvol, pair_b, ld_b, feats.shape[0], flip_b, None, None, False, ctx.d_n_src, ctx.rb)
-        if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dout.sum(0)
-        return dfe, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
+        out = _conv(feats, _packed(weight, 0), cout, kvol, pair_f, ld_f, n_dst, False, None, bias, False, d_n, rb)
+        y, mean, invstd = ops.bn_relu_fwd(out, gamma, beta, running_mean, running_var, momentum, eps, relu,
+                                          num_batches_tracked=nbt)
+        ctx.save_for_backward(feats, weight, out, gamma, beta, mean, invstd)
+        ctx.tables, ctx.rb, ctx.d_n_src, ctx.has_bias, ctx.relu = tables, rb, d_n_src, bias is not None, relu
+        ctx.mark_non_differentiable(running_mean, running_var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        feats, weight, out, gamma, beta, mean, invstd = ctx.saved_tensors
+        dout, dgamma, dbeta = ops.bn_relu_bwd(out, dy, gamma, beta, mean, invstd, ctx.relu)
+        dfe, dw, db = _conv_backward(feats, weight, ctx.tables, ctx.rb, ctx.d_n_src, ctx.has_bias, dout,
+                                     ctx.needs_input_grad[:3])
+        return dfe, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+
+
+def sparse_conv_bn_relu(feats, weight, bias, rb, bn, relu):
+    """sparse_conv (not inverse) followed by `bn` in training mode and optionally ReLU, as one autograd node."""
+    tables = ((rb.pair, rb.ld, rb.n_out, rb.pair, rb.ld, True) if rb.subm else
+              (rb.pair, rb.ld, rb.n_out, rb.pair_bwd, rb.pair_bwd.shape[1], False))
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    return _SparseConvBNReLUFn.apply(feats, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     bn.num_batches_tracked, mom, bn.eps, relu, tables, rb, rb.d_n_out, rb.d_n_in)
 
 
 def sparse_conv(feats, weight, bias, rb, inverse=False, scale=None, shift=None, relu=False):

@@ -9,6 +9,8 @@ Names, constructor arguments, parameter names/shapes and indice_key caching foll
 import math
 from collections import OrderedDict
 
+import os
+
 import torch
 from torch import nn
 
@@ -78,6 +80,13 @@ class SparseSequential(SparseModule):
                     input = module(input, fused=(scale, shift, relu))
                     i += consumed
                     continue
+                pre = _train_bn_pre(module, mods, i, input) if isinstance(input, SparseConvTensor) else None
+                if pre is not None:
+                    # training: conv + BatchNorm1d (batch statistics) + ReLU as one autograd node over the libspx kernels
+                    bn, relu, consumed = pre
+                    input = module(input, train_bn=(bn, relu))
+                    i += consumed
+                    continue
                 input = module(input)
                 tail = _train_bn_tail(mods, i, input) if isinstance(input, SparseConvTensor) else None
                 if tail is not None:
@@ -96,6 +105,25 @@ class SparseSequential(SparseModule):
                 input = module(input)
             i += 1
         return input
+
+
+_FUSED_BLOCK = os.environ.get("SPX_FUSED_BLOCK", "1") != "0"     # dev knob: conv and BN+ReLU as separate autograd nodes
+
+
+def _train_bn_pre(conv, mods, i, x):
+    """(bn, relu, modules consumed) when mods[i:] is a non-inverse SparseConvolution followed by a training-mode
+    BatchNorm1d[, ReLU] that libspx covers — decided before the conv runs, from its out_channels — so that the three run
+    as one autograd node (F_.sparse_conv_bn_relu)."""
+    if (not _FUSED_BLOCK or not is_sparse_conv(conv) or conv.inverse or i + 1 >= len(mods) or x.n_valid is not None
+            or not x.features.is_cuda):
+        return None
+    bn = mods[i + 1]
+    if not (isinstance(bn, nn.BatchNorm1d) and bn.training and bn.affine and bn.track_running_stats
+            and x.features.dtype == torch.float32 and ops.bn_relu_supported(conv.out_channels)
+            and x.features.shape[0] > 1 and torch.is_grad_enabled()):
+        return None
+    relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+    return bn, relu, (3 if relu else 2)
 
 
 def _train_bn_tail(mods, i, x):
@@ -213,13 +241,18 @@ class SparseConvolution(SparseModule):
             x.indice_dict[self.indice_key] = rb
         return rb
 
-    def forward(self, x, fused=None):
+    def forward(self, x, fused=None, train_bn=None):
         assert isinstance(x, SparseConvTensor)
         feats = x.features
         if feats.shape[1] != self.in_channels:
             raise ValueError("channel size mismatch: got %d, conv expects %d" % (feats.shape[1], self.in_channels))
         rb = self._rulebook(x)
-        if fused is not None:
+        if train_bn is not None and not self.inverse and rb.n_out > 1 and rb.n_in > 0:
+            out_feats = F_.sparse_conv_bn_relu(feats, self.weight, self.bias, rb, train_bn[0], train_bn[1])
+        elif train_bn is not None:
+            out_feats = F_.sparse_conv(feats, self.weight, self.bias, rb, inverse=self.inverse)
+            out_feats = F_.bn_act(out_feats, train_bn[0], train_bn[1])
+        elif fused is not None:
             scale, shift, relu = fused      # shift already contains the conv bias
             out_feats = F_.sparse_conv(feats, self.weight, None, rb, inverse=self.inverse, scale=scale, shift=shift,
                                        relu=relu)
