@@ -157,8 +157,8 @@ int spx_conv_rulebook(const int32_t *idx, int64_t n_in, const int64_t *d_n_in, i
  *
  *    Weights arrive in the reference parameter layout  w[Cout][K][Cin]  (= spconv 2.x
  *    weight[Cout,kz,ky,kx,Cin], detector3d_template.py:547-562) and are re-laid for the MFMA operand
- *    order by spx_pack_weight (mode 0: forward operand W_k[ci][co]; mode 1: dgrad operand W_k^T).
- *    packed size = K*Cin*Cout floats in both modes.
+ *    order by spx_pack_weight (mode 0: forward operand W_k[ci][co]; mode 1: dgrad operand W_k^T; mode 2: both in one
+ *    launch, forward operand first).  packed size = K*Cin*Cout floats (twice that for mode 2).
  *
  *    forward : out[o,co] = sum_k sum_ci in[pair[k*ld+o], ci] * w[co][k][ci]          (pair = forward table)
  *    dgrad   : din[i,ci] = sum_k sum_co dout[pairT[k*ld+i], co] * w[co][k][ci]       (pairT = backward table;

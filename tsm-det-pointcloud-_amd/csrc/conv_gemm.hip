@@ -44,10 +44,19 @@ __device__ __forceinline__ float w_elem(const float* w, int cout, int K, int cin
 }
 
 // MFMA order: [k][nt][jg][lane][e]; lane = 16q + c ; k-step j = 4jg + e ; cs = 16jg + 4q + e ; cd = 16nt + c
+// mode 2: both orders in one launch, out[0, total) = forward operand, out[total, 2 total) = dgrad operand
 __global__ void k_pack_mfma(const float* __restrict__ w, int cout, int K, int cin, int mode, int CS, int CD,
                             float* __restrict__ out) {
   int total = K * CS * CD;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mode == 2) {
+    if (t >= 2 * total) return;
+    out += t >= total ? total : 0;
+    mode = t >= total ? 1 : 0;
+    t -= mode * total;
+    CS = mode == 0 ? cin : cout;
+    CD = mode == 0 ? cout : cin;
+  }
   if (t >= total) return;
   int e = t & 3, lane = (t >> 2) & 63;
   int rest = t >> 8;
@@ -66,6 +75,14 @@ __global__ void k_pack_plain(const float* __restrict__ w, int cout, int K, int c
                              float* __restrict__ out) {
   int total = K * CS * CD;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mode == 2) {
+    if (t >= 2 * total) return;
+    out += t >= total ? total : 0;
+    mode = t >= total ? 1 : 0;
+    t -= mode * total;
+    CS = mode == 0 ? cin : cout;
+    CD = mode == 0 ? cout : cin;
+  }
   if (t >= total) return;
   int cd = t % CD, cs = (t / CD) % CS, k = t / (CD * CS);
   out[t] = w_elem(w, cout, K, cin, mode, k, cs, cd);
@@ -895,11 +912,11 @@ static int launch_mfma(const float* src, const float* wp, const int32_t* pair, i
 
 extern "C" int spx_pack_weight(const float* w, int cout, int kvol, int cin, int mode, float* packed,
                                spx_stream_t stream) {
-  if (!w || !packed || cout <= 0 || cin <= 0 || kvol <= 0 || kvol > SPX_MAX_KVOL || (mode != 0 && mode != 1))
+  if (!w || !packed || cout <= 0 || cin <= 0 || kvol <= 0 || kvol > SPX_MAX_KVOL || mode < 0 || mode > 2)
     return SPX_ERR_INVALID_ARG;
-  int CS = mode == 0 ? cin : cout, CD = mode == 0 ? cout : cin;
+  int CS = mode == 1 ? cout : cin, CD = mode == 1 ? cin : cout;
   int total = kvol * CS * CD;
-  unsigned nb = (unsigned)((total + 255) / 256);
+  unsigned nb = (unsigned)(((mode == 2 ? 2 : 1) * total + 255) / 256);
   if (use_mfma(CS, CD))
     hipLaunchKernelGGL(k_pack_mfma, dim3(nb), dim3(256), 0, spx_s(stream), w, cout, kvol, cin, mode, CS, CD, packed);
   else

@@ -10,7 +10,9 @@ from . import ops
 
 def _packed(weight, mode):
     """MFMA-ordered copy of `weight`, cached on the parameter until it is modified in place (optimizer step, load).
-    While a hipGraph is being captured the pack kernel is always recorded, so a replay never reads a stale copy."""
+    When a gradient will be needed both operand orders are produced by ONE launch at forward time and the backward pass
+    finds its half in the cache (the weights do not change in between).  While a hipGraph is being captured the pack
+    kernel is always recorded, so a replay never reads a stale copy."""
     if weight.is_cuda and torch.cuda.is_current_stream_capturing():
         return ops.pack_weight(weight, mode)
     cache = getattr(weight, "_spx_packed", None)
@@ -24,8 +26,14 @@ def _packed(weight, mode):
     hit = cache.get(key)
     if hit is not None and hit[0] == weight._version:
         return hit[1]
-    wp = ops.pack_weight(weight, mode)
     cache.clear()
+    if mode == 0 and weight.requires_grad and torch.is_grad_enabled():
+        both = ops.pack_weight(weight, 2)
+        half = both.numel() // 2
+        cache[key] = (weight._version, both[:half])
+        cache[(1, weight.data_ptr())] = (weight._version, both[half:])
+        return both[:half]
+    wp = ops.pack_weight(weight, mode)
     cache[key] = (weight._version, wp)
     return wp
 
@@ -87,7 +95,7 @@ def _conv_backward(feats, weight, tables, rb, d_n_src, has_bias, dout, needs):
     dout = dout.contiguous()
     dfe = dw = db = None
     if needs[0]:
-        wt = ops.pack_weight(weight, 1)
+        wt = _packed(weight, 1)
         dfe = _conv(dout, wt, cin, kvol, pair_b, ld_b, feats.shape[0], flip_b, None, None, False, d_n_src, rb)
     if needs[1]:
         dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape))

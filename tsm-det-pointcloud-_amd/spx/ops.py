@@ -220,15 +220,15 @@ def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, di
 # ------------------------------------------------------------------------------------------- arithmetic
 
 def pack_weight(weight, mode):
-    """weight [Cout, kz, ky, kx, Cin] (or [Cout, K, Cin]) -> MFMA operand order.  mode 0 fwd, 1 dgrad."""
+    """weight [Cout, kz, ky, kx, Cin] (or [Cout, K, Cin]) -> MFMA operand order.  mode 0 fwd, 1 dgrad, 2 both."""
     _need_gpu(weight)
     lib = _lib.load()
     w = weight.detach().contiguous().float()
     cout, cin = w.shape[0], w.shape[-1]
     K = w.numel() // (cout * cin)
-    packed = torch.empty((K * cin * cout,), dtype=torch.float32, device=w.device)
+    packed = torch.empty(((2 if mode == 2 else 1) * K * cin * cout,), dtype=torch.float32, device=w.device)
     check(lib.spx_pack_weight(_ptr(w), cout, K, cin, mode, _ptr(packed), _stream(w)), "spx_pack_weight")
-    return packed
+    return packed                # mode 2: forward operand in the first half, dgrad operand in the second
 
 
 def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False,
