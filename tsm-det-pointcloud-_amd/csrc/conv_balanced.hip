@@ -122,6 +122,7 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t n, const int64_t* d_
     pre[T4] = U;
     int nb = U / 8;                       // at least 8 super-units per workgroup
     if (nb > kBlocks) nb = kBlocks;
+    if (nb >= 8) nb &= ~7;                // a multiple of 8: the XCD-contiguous numbering of the main kernel needs it
     if (nb < 1) nb = U > 0 ? 1 : 0;
     plan[0] = nb;
     plan[1] = U;
@@ -170,9 +171,16 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
   (void)occupancy_pad;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int blk = blockIdx.x;
   const int nb = plan[0];
-  if (blk >= nb) return;                    // whole workgroup: no barrier has been reached yet
+  if ((int)blockIdx.x >= nb) return;        // whole workgroup: no barrier has been reached yet
+  // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  Renumber so that XCD x walks a CONTIGUOUS eighth of the
+  // super-unit list: neighbouring destination rows gather overlapping source rows, and each XCD's private L2 then
+  // holds one eighth of the feature matrix (plus halo) instead of a sample of all of it.
+#ifndef SPX_CB_NO_XCD
+  const int blk = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+#else
+  const int blk = blockIdx.x;
+#endif
   const int U = plan[1], T4 = plan[2];
   const int64_t nlive = spx_live_n(d_n, n);
   const int32_t* mask = plan + plan_off_mask();
