@@ -314,7 +314,7 @@ def test_conv_balanced_schedule_matches_tile_per_wave(orc):
     cases = [(sub.pair, sub.ld, sub.n_out, sub.n_in, False), (sub.pair, sub.ld, sub.n_in, sub.n_out, True),
              (strd.pair, strd.ld, strd.n_out, strd.n_in, False),
              (strd.pair_bwd, strd.pair_bwd.shape[1], strd.n_in, strd.n_out, False)]
-    for (cs, cd) in ((64, 64), (32, 64), (64, 32), (32, 32)):
+    for (cs, cd) in ((64, 64), (32, 64), (64, 32), (32, 32), (128, 128)):     # 128x128: the two-half kernel
         w = (torch.randn(cd, 3, 3, 3, cs, generator=g) / np.sqrt(27 * cs)).to(dev)
         wp = ops.pack_weight(w, 0)
         for pair, ld, n_dst, n_src, flip in cases:
@@ -362,7 +362,7 @@ def test_conv_grouped_row_order(frames, n_live, orc):
     plan_c = ops.conv_plan(sub.pair, sub.ld, K, n, d_n)
     plan_g = ops.conv_plan(grouped, n, K, n, d_n)
     assert int(plan_g[1]) < int(plan_c[1])                              # fewer MFMA units to issue
-    for cs, cd in ((64, 64), (32, 32)):
+    for cs, cd in ((64, 64), (32, 32), (128, 128)):
         w = (torch.randn(cd, 3, 3, 3, cs, generator=g) / np.sqrt(27 * cs)).to(dev)
         wp = ops.pack_weight(w, 0)
         x = torch.randn(n, cs, generator=g).to(dev)
@@ -394,6 +394,13 @@ def test_conv_balanced_small_and_ragged_sizes(n):
     for flip in (False, True):
         ref = ops.conv_gemm(x, wp, 64, 27, rb.pair, rb.ld, n, flip_k=flip)
         out = ops.conv_gemm_balanced(x, wp, 64, 27, rb.pair, rb.ld, n, plan, flip_k=flip)
+        assert _rel_t(out, ref) < 2e-6
+    # the two-half 128 -> 128 kernel (two virtual workgroups per physical one) on the same ragged tables
+    x2 = torch.randn(n, 128, generator=g).to(dev)
+    w2 = ops.pack_weight((torch.randn(128, 3, 3, 3, 128, generator=g) / np.sqrt(27 * 128)).to(dev), 0)
+    for flip in (False, True):
+        ref = ops.conv_gemm(x2, w2, 128, 27, rb.pair, rb.ld, n, flip_k=flip)
+        out = ops.conv_gemm_balanced(x2, w2, 128, 27, rb.pair, rb.ld, n, plan, flip_k=flip)
         assert _rel_t(out, ref) < 2e-6
 
 

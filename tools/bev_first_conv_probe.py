@@ -65,6 +65,7 @@ def main():
     # sparse form
     ks, st, pd = (D, 3, 3), (1, 1, 1), (0, 1, 1)
     rb = ops.conv_rulebook(idx, batch, shape, ks, st, pd)
+    dout = torch.randn(rb.n_out, CO, generator=g).to(dev)
     t_rb = timeit(lambda: ops.conv_rulebook(idx, batch, shape, ks, st, pd), 10)
     K = rb.kvol
     P = int((rb.pair[:, :rb.n_out] >= 0).sum())
@@ -80,11 +81,30 @@ def main():
         rb.n_out, rb.n_out / (batch * H * W), K, P, err, rest))
     flops = 2.0 * P * C * CO
     t_f = timeit(lambda: ops.conv_gemm(feats, wp, CO, K, rb.pair, rb.ld, rb.n_out), 20)
-    dout = torch.randn(rb.n_out, CO, generator=g).to(dev)
     t_d = timeit(lambda: ops.conv_gemm(dout, wt, C, K, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in), 20)
     t_w = timeit(lambda: ops.conv_wgrad(feats, dout, rb.pair, rb.ld, rb.n_out, tuple(w3.shape)), 20)
     out_shape = rb.out_shape
     t_dn = timeit(lambda: ops.densify(ys, rb.out_indices, batch, out_shape, channels_last=True), 20)
+    # balanced two-half kernel (plan over the table), and the same over rows grouped by offset mask
+    os.environ.setdefault("SPX_CONV_BALANCED_SHAPES", "128x128")
+    plan = ops.conv_plan(rb.pair, rb.ld, K, rb.n_out)
+    yb = ops.conv_gemm_balanced(feats, wp, CO, K, rb.pair, rb.ld, rb.n_out, plan)
+    t_fb = timeit(lambda: ops.conv_gemm_balanced(feats, wp, CO, K, rb.pair, rb.ld, rb.n_out, plan), 20)
+    perm, grouped = ops.conv_group(rb.pair, rb.ld, K, rb.n_out)
+    plang = ops.conv_plan(grouped, rb.n_out, K, rb.n_out)
+    yg = ops.conv_gemm_balanced(feats, wp, CO, K, grouped, rb.n_out, rb.n_out, plang, perm=perm)
+    t_fg = timeit(lambda: ops.conv_gemm_balanced(feats, wp, CO, K, grouped, rb.n_out, rb.n_out, plang, perm=perm), 20)
+    t_grp = timeit(lambda: ops.conv_group(rb.pair, rb.ld, K, rb.n_out), 20)
+    t_pl = timeit(lambda: ops.conv_plan(rb.pair, rb.ld, K, rb.n_out), 20)
+    nb_ = rb.pair_bwd.shape[1]
+    planb = ops.conv_plan(rb.pair_bwd, nb_, K, rb.n_in)
+    db_ref = ops.conv_gemm(dout, wt, C, K, rb.pair_bwd, nb_, rb.n_in)
+    db_bal = ops.conv_gemm_balanced(dout, wt, C, K, rb.pair_bwd, nb_, rb.n_in, planb)
+    t_db = timeit(lambda: ops.conv_gemm_balanced(dout, wt, C, K, rb.pair_bwd, nb_, rb.n_in, planb), 20)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    print("balanced 128x128: fwd %6.1f us (err %.1e, units %d) | fwd grouped %6.1f us (err %.1e, units %d; group %5.1f us, plan %5.1f us)"
+          " | dgrad %6.1f us (err %.1e)" % (t_fb * 1e6, rel(yb, ys), int(plan[1]), t_fg * 1e6, rel(yg, ys), int(plang[1]),
+                                            t_grp * 1e6, t_pl * 1e6, t_db * 1e6, rel(db_bal, db_ref)))
     print("sparse rulebook %6.1f us | fwd %6.1f us (%.1f TF/s) | dgrad %6.1f us | wgrad %6.1f us | densify out %6.1f us | sum %.1f us" % (
         t_rb * 1e6, t_f * 1e6, flops / t_f / 1e12, t_d * 1e6, t_w * 1e6, t_dn * 1e6, (t_rb + t_f + t_d + t_w + 2 * t_dn) * 1e6))
 

@@ -237,6 +237,8 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
             (__attribute__((address_space(3))) void*)(&sB[buf][f * 64]), 16, 0, 0);
     }
   };
+  // (Returning the entry raw and applying its validity at the consumers removes the wait the compiler puts right behind
+  // this load, but the kernel then runs 5 % SLOWER — measured, same call — so the select stays here.)
   auto load_id = [&](const Cur& c) -> int32_t {              // unconditional (row clamped); -1 where not applicable
     const int S = c.S >= 0 ? c.S : 0;
     const int64_t row = (int64_t)S * kRows + 16 * wave + r;
@@ -369,6 +371,185 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
 #endif
 }
 
+// ---------------------------------------------------------------- the same schedule for wide layers (128 channels)
+// A 128x128 weight slice is 64 KiB: two of them do not fit the static LDS budget, and a one-tile-per-wave kernel re-reads
+// the slice per 16 rows (1.7 GB L2 -> CU per launch for the BEV entry conv, its bound).  Here the destination columns
+// are multiplied in two halves: half h of W_k lives in LDS buffer h (32 KiB each), a super-unit is two sub-steps
+//   barrier ; issue {rule entries of c2, rows of c1, W_k half 1 -> buffer 1} ; MFMA half 0 from buffer 0
+//   barrier ; issue {W_k' half 0 of the next super-unit -> buffer 0}          ; MFMA half 1 from buffer 1
+// so every copy has a whole sub-step (4096 MFMA cycles) to land.  64 KiB of LDS per workgroup = two workgroups per CU;
+// the plan still deals its ranges to up to 1024 virtual workgroups, each physical workgroup walks two of them one after
+// the other (same partial-sum slots, same fix-up kernel, same bits as a 1024-workgroup launch would give).
+template <int CS, int CD>
+__global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv_mfma_pbl2(
+    const float* __restrict__ src, const float* __restrict__ wp, const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
+    int64_t n, const int64_t* d_n, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+    const int32_t* __restrict__ plan, int64_t t4cap, const int32_t* __restrict__ perm, float* __restrict__ dst,
+    float* __restrict__ scratch) {
+  static_assert(kWpb == 4, "two-half kernel is written for 4 waves per workgroup");
+  constexpr int NT = CD / 16;
+  constexpr int NTH = NT / 2;               // column tiles per half
+  constexpr int JG = CS / 16;
+  constexpr int NF = NT * JG;               // 1 KiB weight fragments per offset
+  constexpr int NFH = NTH * JG;             // per half
+  __shared__ f32x4 sB[2][NFH * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int nb = plan[0];
+  const int np = (nb + 1) >> 1;             // physical workgroups that have work
+  if ((int)blockIdx.x >= np) return;        // whole workgroup: no barrier has been reached yet
+  const int lb = (np & 7) == 0 ? (int)(blockIdx.x & 7) * (np >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // XCD-contiguous
+  const int U = plan[1], T4 = plan[2];
+  const int64_t nlive = spx_live_n(d_n, n);
+  const int32_t* mask = plan + plan_off_mask();
+  const int32_t* pre = plan + plan_off_pre(t4cap);
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+
+  for (int vv = 0; vv < 2; ++vv) {
+    const int blk = 2 * lb + vv;            // virtual workgroup of the plan
+    if (blk >= nb) break;
+    __syncthreads();                        // the previous virtual workgroup's last reads of the LDS buffers are done
+    const int u0 = block_u0(blk, U, nb), u1 = block_u0(blk + 1, U, nb);
+    const int s_first = plan[plan_off_wstart() + blk];
+    struct Cur {
+      int S, k;
+      uint32_t mself;
+      int whole;
+    };
+    int it_S = s_first - 1;
+    uint32_t it_todo = 0, it_mself = 0;
+    int it_whole = 0;
+    auto next = [&]() -> Cur {
+      while (it_todo == 0) {
+        ++it_S;
+        if (it_S >= T4) return Cur{-1, 0, 0u, 0};
+        const int p0 = pre[it_S];
+        if (p0 >= u1) return Cur{-1, 0, 0u, 0};
+        const int work = pre[it_S + 1] - p0;
+        if (work == 0) continue;
+        const int4 m4 = *reinterpret_cast<const int4*>(mask + (size_t)kWpb * it_S);
+        const uint32_t many = (uint32_t)(m4.x | m4.y | m4.z | m4.w);
+        it_mself = (uint32_t)mask[(size_t)kWpb * it_S + wave];
+        it_whole = (u0 <= p0 && p0 + work <= u1) ? 1 : 0;
+        int c = p0;
+        for (int k = 0; k < K; ++k) {
+          const int tr = flip ? K - 1 - k : k;
+          if (!((many >> tr) & 1u)) continue;
+          if (c >= u0 && c < u1) it_todo |= 1u << k;
+          ++c;
+        }
+      }
+      const int k = __ffs((int)it_todo) - 1;
+      it_todo &= it_todo - 1;
+      return Cur{it_S, k, it_mself, it_whole};
+    };
+    auto copy_w = [&](int k, int h) {       // half h of W_k -> LDS buffer h
+#pragma unroll
+      for (int i = 0; i < NFH / kWpb; ++i) {
+        const int f = wave + i * kWpb;      // wave-uniform
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wp4 + ((size_t)k * NF + (size_t)h * NFH + f) * 64 + lane),
+            (__attribute__((address_space(3))) void*)(&sB[h][f * 64]), 16, 0, 0);
+      }
+    };
+    auto load_id = [&](const Cur& c) -> int32_t {
+      const int S = c.S >= 0 ? c.S : 0;
+      const int64_t row = (int64_t)S * kRows + 16 * wave + r;
+      const int64_t rc = row < nlive ? row : nlive - 1;
+      const int32_t v = pair[(int64_t)(flip ? K - 1 - c.k : c.k) * ld + rc];
+      return (c.S >= 0 && row < nlive) ? v : -1;
+    };
+    auto gather = [&](int32_t id, f32x4 (&a)[JG]) {
+      const float* p = src + (size_t)(id > 0 ? id : 0) * CS + 4 * q;
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) a[jg] = *reinterpret_cast<const f32x4*>(p + 16 * jg);
+    };
+    auto mma_half = [&](int h, const f32x4 (&a)[JG], bool live, f32x4 (&acc)[NT]) {
+      const f32x4* B = sB[h];
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) {
+        f32x4 b[NTH];
+#pragma unroll
+        for (int nt = 0; nt < NTH; ++nt) b[nt] = B[(nt * JG + jg) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float av = live ? a[jg][e] : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NTH; ++nt)
+            acc[h * NTH + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt][e], acc[h * NTH + nt], 0, 0, 0);
+        }
+      }
+    };
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Cur c0 = next(), c1 = next(), c2 = next();
+    int32_t id0 = load_id(c0), id1 = load_id(c1);
+    if (c0.S >= 0) copy_w(c0.k, 0);
+    f32x4 a_cur[JG], a_nxt[JG];
+    gather(id0, a_cur);
+    while (c0.S >= 0) {
+      const int tr0 = flip ? K - 1 - c0.k : c0.k;
+      const bool active = (c0.mself >> tr0) & 1u;      // wave-uniform: this wave's tile has the offset
+      __syncthreads();   // half 0 of W(c0) landed for every wave, a_cur / id1 arrived; buffer 1 is free again
+      const int32_t id2 = load_id(c2);
+      gather(id1, a_nxt);
+      copy_w(c0.k, 1);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const bool live0 = id0 >= 0;
+      if (active) mma_half(0, a_cur, live0, acc);
+      __syncthreads();   // half 1 of W(c0) landed; buffer 0 is free again
+      if (c1.S >= 0) copy_w(c1.k, 0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (active) mma_half(1, a_cur, live0, acc);
+      if (c1.S != c0.S) {
+        const int64_t row_base = (int64_t)c0.S * kRows + 16 * wave;
+        if (c0.whole) {
+          int64_t drow[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int64_t orow = row_base + 4 * q + e;
+            drow[e] = orow < nlive ? (perm ? (int64_t)perm[orow] : orow) : -1;
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int col = 16 * nt + r;
+            const float sc = scale ? scale[col] : 1.0f;
+            const float sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (drow[e] >= 0) {
+                float v = acc[nt][e];
+                if (scale || shift) v = v * sc + sh;
+                if (relu) v = v > 0.f ? v : 0.f;
+                dst[drow[e] * CD + col] = v;
+              }
+            }
+          }
+        } else {
+          float* out = scratch + ((size_t)2 * blk + (c0.S == s_first ? 0 : 1)) * (kRows * CD) + (size_t)(16 * wave) * CD;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[(4 * q + e) * CD + 16 * nt + r] = acc[nt][e];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) a_cur[jg] = a_nxt[jg];
+      id0 = id1;
+      id1 = id2;
+      c0 = c1;
+      c1 = c2;
+      c2 = next();
+    }
+  }
+}
+
 // ---------------------------------------------------------------- shared super-tiles: sum the partials in workgroup order
 template <int CD>
 __global__ __launch_bounds__(256) void k_conv_fixup(const int32_t* __restrict__ plan, int64_t t4cap, int64_t n,
@@ -439,6 +620,17 @@ static void launch_pb(const float* src, const float* wp, const int32_t* pair, in
                      relu, perm, scratch, dst);
 }
 
+template <int CS, int CD>
+static void launch_pb2(const float* src, const float* wp, const int32_t* pair, int64_t ld, int K, int flip, int64_t n,
+                       const int64_t* d_n, const float* scale, const float* shift, int relu, const int32_t* plan,
+                       const int32_t* perm, float* dst, float* scratch, hipStream_t s) {
+  const int64_t t4cap = tiles4_cap(n);
+  hipLaunchKernelGGL((k_conv_mfma_pbl2<CS, CD>), dim3(kBlocks / 2), dim3(64 * kWpb), 0, s, src, wp, pair, ld, K, flip, n, d_n,
+                     scale, shift, relu, plan, t4cap, perm, dst, scratch);
+  hipLaunchKernelGGL((k_conv_fixup<CD>), dim3((unsigned)((n + kRows - 1) / kRows)), dim3(256), 0, s, plan, t4cap, n, d_n, scale, shift,
+                     relu, perm, scratch, dst);
+}
+
 }  // namespace
 
 extern "C" size_t spx_conv_plan_bytes(int64_t n_dst) {
@@ -486,5 +678,11 @@ extern "C" int spx_conv_gemm_balanced(const float* src, int c_src, const float* 
   SPX_PB_CASE(32, 64)
   SPX_PB_CASE(64, 32)
   SPX_PB_CASE(64, 64)
+  if (c_src == 128 && c_dst == 128 && kWpb == 4) {
+    launch_pb2<128, 128>(src, w_packed, pair, pair_ld, kvol, flip_k, n_dst, d_n_dst, scale, shift, relu, plan, perm, dst, scratch,
+                         s);
+    SPX_CHECK_LAUNCH();
+    return SPX_OK;
+  }
   return SPX_ERR_UNSUPPORTED;   // other channel pairs: use spx_conv_gemm
 }

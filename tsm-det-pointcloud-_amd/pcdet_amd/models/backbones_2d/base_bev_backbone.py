@@ -50,6 +50,7 @@ def _run_block(seq, x, start=0):
 
 _SPARSE_ENTRY = os.environ.get("SPX_BEV_SPARSE_ENTRY", "1") != "0"     # dev knob
 _FUSED_CAT = os.environ.get("SPX_BEV_FUSED_CAT", "1") != "0"            # dev knob
+_WIDE_BALANCED = os.environ.get("SPX_BEV_WIDE_BALANCED", "1") != "0"    # dev knob
 _SPARSE_ENTRY_CHANNELS = (16, 32, 64, 128)                                # MFMA instantiations of libspx's conv kernels
 
 
@@ -91,6 +92,7 @@ def _sparse_entry(seq, bev):
                                d_n_in=src.n_valid, cap=(src.static_caps or {}).get('bev_entry', None), sync=False)
     if rb.n_out == 0:
         return None
+    rb.wide_balanced_fwd = _WIDE_BALANCED   # 128 -> 128 forward through the two-half balanced kernel (spx/ops.py: balanced_ok)
     # Conv2d weight [Co, c*D + z, ky, kx] -> sparse layout [Co, z, ky, kx, c]; a view, so the gradient lands in conv.weight
     w3 = conv.weight.view(conv.out_channels, c, d, kh, kw).permute(0, 2, 3, 4, 1)
     rows = sparse_conv(feats, w3, None, rb)

@@ -43,7 +43,7 @@ def _conv(src, wp, c_dst, kvol, pair, ld, n_dst, flip, scale, shift, relu, d_n, 
     over rows grouped by offset mask for submanifold tables, which several launches share), the one-tile-per-wave
     kernel otherwise."""
     if (rb is not None and src.is_cuda and n_dst > 0 and src.shape[0] > 0
-            and ops.balanced_ok(src.shape[1], c_dst, n_dst)):
+            and ops.balanced_ok(src.shape[1], c_dst, n_dst, rb, pair)):
         if ops.grouped_ok(rb, kvol):
             perm, grouped, plan = ops.grouped_plan_for(rb, pair, ld, kvol, n_dst, d_n)
             return ops.conv_gemm_balanced(src, wp, c_dst, kvol, grouped, n_dst, n_dst, plan, flip_k=flip, scale=scale,

@@ -307,8 +307,15 @@ def grouped_ok(rb, kvol):
     return _GROUPED and rb.subm and kvol <= 30
 
 
-def balanced_ok(c_src, c_dst, n_dst):
-    return _BALANCED and (c_src, c_dst) in _BALANCED_SHAPES and n_dst >= _BALANCED_MIN_ROWS
+def balanced_ok(c_src, c_dst, n_dst, rb=None, pair=None):
+    if not _BALANCED or n_dst < _BALANCED_MIN_ROWS:
+        return False
+    if (c_src, c_dst) in _BALANCED_SHAPES:
+        return True
+    # 128 -> 128: the two-half kernel (k_conv_mfma_pbl2) beats one tile per wave on tables whose 64-row super-tiles
+    # really share their offsets — the forward table of the BEV entry conv (313 -> 209 us); on its backward table, where
+    # every row has 9 of the 18 offsets, it loses (185 vs 165 us).  The caller marks the rulebook.
+    return (c_src, c_dst) == (128, 128) and rb is not None and getattr(rb, "wide_balanced_fwd", False) and pair is rb.pair
 
 
 def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k=False, scale=None, shift=None,
