@@ -31,7 +31,20 @@ __global__ __launch_bounds__(1024) void k_count_pos(const int32_t* __restrict__ 
   __shared__ int s[16];
   const int b = blockIdx.x;
   int c = 0;
-  for (int64_t a = threadIdx.x; a < A; a += 1024) c += labels[(int64_t)b * A + a] > 0 ? 1 : 0;
+  const int32_t* row = labels + (int64_t)b * A;
+  if ((A & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+    // 16-byte loads, four in flight per thread: one block per frame walks 211 200 labels, and with one dependent 4-byte
+    // load per trip this kernel took 34 us
+    const int4* row4 = reinterpret_cast<const int4*>(row);
+    const int64_t A4 = A >> 2;
+#pragma unroll 4
+    for (int64_t a = threadIdx.x; a < A4; a += 1024) {
+      const int4 v = row4[a];
+      c += (v.x > 0) + (v.y > 0) + (v.z > 0) + (v.w > 0);
+    }
+  } else {
+    for (int64_t a = threadIdx.x; a < A; a += 1024) c += row[a] > 0 ? 1 : 0;
+  }
   for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
   __syncthreads();

@@ -128,7 +128,7 @@ __global__ void k_mark(const int32_t* __restrict__ idx, int64_t n, const int64_t
   atomicOr(reinterpret_cast<unsigned long long*>(&bits[key >> 6]), 1ull << (key & 63));
 }
 
-constexpr int kWordsPerThread = 8;
+constexpr int kWordsPerThread = 1;   // one 64-cell word per thread: coalesced 8-byte loads, and the small dense grids of the deep levels (2-12 blocks at 8 words per thread, each thread decoding up to 8 x 64 cells serially: 30-48 us) spread over the chip
 constexpr int kWordsPerBlock = kBlock * kWordsPerThread;
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
