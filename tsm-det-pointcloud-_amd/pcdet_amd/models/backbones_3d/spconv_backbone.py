@@ -5,8 +5,10 @@ The 12 sparse convolutions (8 SubM k3, 3 strided k3 s2, 1 k(3,1,1) s(2,1,1)) run
 BatchNorm1d(eps=1e-3, momentum=0.01) + ReLU stay torch.nn modules so parameter names (`conv2.0.1.weight` ...)
 and train/eval behaviour are unchanged.
 """
+import os
 from functools import partial
 
+import torch
 import torch.nn as nn
 
 import spx as spconv
@@ -60,16 +62,60 @@ class SparseBasicBlock(spconv.SparseModule):
         return out
 
 
+_AHEAD = os.environ.get("SPX_TABLES_AHEAD", "1") != "0"      # dev knob
+
+
+class _TablesAhead(object):
+    """Launch the strided rule table of the NEXT stage early, collect it late (see _run_8x_stack)."""
+
+    def __init__(self, x):
+        self.on = (_AHEAD and x.features.is_cuda and x.n_valid is None and x.indices.shape[0] > 0
+                   and not torch.cuda.is_current_stream_capturing())
+        self.book, self.batch = x.indice_dict, x.batch_size
+        self.pending = None
+
+    @staticmethod
+    def _first_strided(stage):
+        for m in stage.modules():
+            if isinstance(m, spconv.SparseConvolution):
+                return m if (not m.subm and not m.inverse and m.indice_key is not None) else None
+        return None
+
+    def launch(self, stage, indices, shape):
+        m = self._first_strided(stage) if (self.on and stage is not None) else None
+        if m is None or m.indice_key in self.book or indices.shape[0] == 0:
+            self.pending = None
+            return
+        self.pending = (m.indice_key, spconv.ops.conv_rulebook(indices, self.batch, shape, m.kernel_size, m.stride,
+                                                               m.padding, m.dilation, sync="later"))
+
+    def collect_and_launch(self, next_stage):
+        if self.pending is None:
+            return
+        key, pend = self.pending
+        rb = self.book[key] = pend.finish()
+        self.launch(next_stage, rb.out_indices, rb.out_shape)
+
+
 def _run_8x_stack(self, batch_dict, with_points_keys):
     voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
     x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(), spatial_shape=self.sparse_shape,
                                 batch_size=batch_dict['batch_size'], n_valid=batch_dict.get('voxel_num_valid', None),
                                 static_caps=batch_dict.get('static_caps', None))
+    # A strided rule table has to tell the host its row count.  Each one is LAUNCHED one stage early — its kernels sit in
+    # the stream in front of the previous stage's convolutions — and its count is picked up after that stage has been
+    # queued, so the host never waits on an empty GPU (same tables, found by the modules under their indice_key).
+    ahead = _TablesAhead(x)
+    ahead.launch(self.conv2, x.indices, x.spatial_shape)
     x = self.conv_input(x)
     x_conv1 = self.conv1(x)
+    ahead.collect_and_launch(self.conv3)
     x_conv2 = self.conv2(x_conv1)
+    ahead.collect_and_launch(self.conv4)
     x_conv3 = self.conv3(x_conv2)
+    ahead.collect_and_launch(self.conv_out)
     x_conv4 = self.conv4(x_conv3)
+    ahead.collect_and_launch(None)
     out = self.conv_out(x_conv4)
     batch_dict['encoded_spconv_tensor'] = out
     batch_dict['encoded_spconv_tensor_stride'] = 8

@@ -183,7 +183,8 @@ def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1),
 
 def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1), want_cnt=False,
                   d_n_in=None, cap=None, sync=True):
-    """Regular sparse conv rulebook.  sync=True: one host sync (reads n_out), exact-size out_indices.
+    """Regular sparse conv rulebook.  sync=True: one host sync (reads n_out), exact-size out_indices; sync="later": a
+    PendingRulebook whose .finish() does that read.
     sync=False (static-capacity / graph mode): no sync; `cap` output rows (default: the no-overflow bound), live counts
     in rb.d_n_in / rb.d_n_out; rows beyond cap are dropped (overflow <=> rb.d_n_out > cap)."""
     _need_gpu(indices)
@@ -211,10 +212,41 @@ def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, di
                       ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation))
         rb.d_n_in, rb.d_n_out = d_n_in, d_n
         return rb
+    if sync == "later":
+        # The row count is read back asynchronously; .finish() waits for it.  A caller that launches this table one stage
+        # early (before it queues the previous stage's kernels) finds the count already there: the host never waits on an
+        # empty GPU (pcdet_amd/models/backbones_3d/spconv_backbone.py).
+        return PendingRulebook(d_n, lambda n_out: Rulebook(
+            pair_fwd, cap, n_in, n_out, K, False, out_idx[:n_out], out_shape, spatial_shape, pair_bwd=pair_bwd, cnt=cnt,
+            ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation)))
     n_out = int(d_n.item())
     rb = Rulebook(pair_fwd, cap, n_in, n_out, K, False, out_idx[:n_out], out_shape, spatial_shape, pair_bwd=pair_bwd,
                   cnt=cnt, ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation))
     return rb
+
+
+class PendingRulebook(object):
+    """A strided rule table whose kernels are queued and whose row count is on its way to the host."""
+
+    _pool, _next = [], 0             # pinned host words, reused round-robin (pinning memory costs far more than the copy)
+
+    def __init__(self, d_n, make):
+        cls = PendingRulebook
+        if len(cls._pool) < 16:
+            cls._pool.append(torch.empty((1,), dtype=torch.int64).pin_memory())
+            self._host = cls._pool[-1]
+        else:
+            self._host = cls._pool[cls._next % 16]
+            cls._next += 1
+        self._make = make
+        self._host.copy_(d_n, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record(torch.cuda.current_stream(d_n.device))
+        self._d_n = d_n                          # keeps the source of the copy alive
+
+    def finish(self):
+        self._event.synchronize()
+        return self._make(int(self._host[0]))
 
 
 # ------------------------------------------------------------------------------------------- arithmetic
