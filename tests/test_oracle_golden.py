@@ -180,3 +180,33 @@ def test_voxel_query_oracle_against_bruteforce(strides, former, orc):
     if strides == (1, 1, 1) and former == 0.0:
         i_plain, c_plain = orc.voxel_query(q_xyz, xyz, q_coords, table, nsample, radius, ranges)
         assert np.array_equal(i_plain, idx) and np.array_equal(c_plain, cnt)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_bev_entry_identity_on_cpu(stride, orc):
+    """The identity BaseBEVBackbone's sparse entry relies on (pcdet_amd/models/backbones_2d/base_bev_backbone.py:
+    _sparse_entry), checked with the CPU oracle and torch-CPU only: ZeroPad2d(1) + Conv2d(C*D, Co, 3, stride s, bias=False)
+    over HeightCompression's map [B, C*D, H, W] (channel = c*D + z, reference height_compression.py:21-23) equals the sparse
+    convolution of the encoded tensor with kernel (D,3,3), stride (1,s,s), padding (0,1,1) and weight
+    W3[co, z, ky, kx, c] = W2[co, c*D + z, ky, kx], scattered to the output pixels — and is exactly zero elsewhere."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(11 + stride)
+    B, D, H, W, C, CO = 2, 2, 14, 12, 6, 5
+    occ = rng.random((B, D, H, W)) < 0.15
+    idx = np.argwhere(occ).astype(np.int32)                                  # (b, z, y, x) ascending
+    feats = rng.standard_normal((idx.shape[0], C)).astype(np.float32)
+    w2 = rng.standard_normal((CO, C * D, 3, 3)).astype(np.float32)
+    dense = np.zeros((B, C, D, H, W), np.float32)
+    dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]] = feats
+    bev = torch.from_numpy(dense.reshape(B, C * D, H, W))
+    yd = F.conv2d(bev, torch.from_numpy(w2), None, stride, 1).numpy()       # [B, CO, Ho, Wo]
+    out_idx, pair_f, _pb, _cnt, out_shape = orc.conv_rulebook(idx, [D, H, W], (D, 3, 3), (1, stride, stride), (0, 1, 1))
+    assert list(out_shape) == [1, yd.shape[2], yd.shape[3]] and (out_idx[:, 1] == 0).all()
+    w3 = np.ascontiguousarray(w2.reshape(CO, C, D, 3, 3).transpose(0, 2, 3, 4, 1))        # [co, z, ky, kx, c]
+    ys = orc.conv_fwd(feats, w3.reshape(CO, D * 9, C), pair_f)
+    got = yd.transpose(0, 2, 3, 1)[out_idx[:, 0], out_idx[:, 2], out_idx[:, 3]]
+    assert np.abs(ys - got).max() < 1e-5 * max(1.0, np.abs(got).max())
+    covered = np.zeros((B, yd.shape[2], yd.shape[3]), bool)
+    covered[out_idx[:, 0], out_idx[:, 2], out_idx[:, 3]] = True
+    assert np.abs(yd.transpose(0, 2, 3, 1)[~covered]).max() == 0.0
