@@ -785,12 +785,23 @@ __global__ void k_conv_valu(const float* __restrict__ src, int CS, const float* 
   int cd = (int)(t % CD);
   if (row >= spx_live_n(d_n, n)) return;
   float acc = 0.f;
-  for (int k = 0; k < K; ++k) {
-    int32_t id = pair[(int64_t)(flip ? K - 1 - k : k) * ld + row];
-    if (id < 0) continue;
-    const float* x = src + (size_t)id * CS;
-    const float* ww = wp + (size_t)k * CS * CD + cd;
-    for (int cs = 0; cs < CS; ++cs) acc = fmaf(x[cs], ww[(size_t)cs * CD], acc);
+  // rule entries nine at a time, unconditionally: one memory round trip per nine offsets instead of one per offset
+  // (a load behind the `continue` of the previous offset is a dependent load: 27 latencies in a row, 37 us for conv_input)
+  for (int k0 = 0; k0 < K; k0 += 9) {
+    int32_t id[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int k = k0 + u < K ? k0 + u : K - 1;
+      id[u] = pair[(int64_t)(flip ? K - 1 - k : k) * ld + row];
+    }
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int k = k0 + u;
+      if (k >= K || id[u] < 0) continue;
+      const float* x = src + (size_t)id[u] * CS;
+      const float* ww = wp + (size_t)k * CS * CD + cd;
+      for (int cs = 0; cs < CS; ++cs) acc = fmaf(x[cs], ww[(size_t)cs * CD], acc);
+    }
   }
   if (scale || shift) acc = acc * (scale ? scale[cd] : 1.f) + (shift ? shift[cd] : 0.f);
   if (relu) acc = acc > 0.f ? acc : 0.f;
