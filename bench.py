@@ -11,7 +11,15 @@ BaseBEVBackbone -> AnchorHeadSingle -> target assignment + losses -> backward ->
 on points already resident in HBM.  Frames are sharded over ranks (weak scaling); the only collective is DDP's
 gradient all-reduce (RCCL over xGMI).  Rank 0 prints ONE JSON line.
 
+`--gpus N` without a torchrun environment: the parent starts the N ranks itself (torch.distributed.run, 127.0.0.1) BEFORE
+it touches the GPU, forwards rank 0's line and exits with the children's code; under torchrun WORLD_SIZE must equal --gpus.
+
 Besides the contract fields the line carries
+  extras        (N = 1 only, each timed in-process after the headline) `forward` (cfg 2 full detector, eager and one
+                hipGraph), `backbone_forward` (voxelise -> VoxelBackBone8x -> densify only, eager and hipGraph, with its own
+                roofline from the per-layer algorithmic bytes / FLOPs of SURVEY.md §8(d)), `rulebook_mvoxels_s` (submanifold
+                and strided tables), `cfg3_fwd_bwd` (Waymo 2 x 80k voxels, full training step) and `cfg5_forward` (Waymo
+                5-frame concat, 300k voxels);
   roofline      for the dominant hand-written kernel, from HIP events recorded around every launch of it on the
                 launch stream during extra instrumented steps of the same workload (the timed region itself runs
                 un-instrumented), algorithmic FLOPs/bytes per SURVEY.md §8(d);
@@ -52,6 +60,7 @@ def parse():
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen find mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward / backbone / rulebook / Waymo extras")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     return ap.parse_args()
 
@@ -353,16 +362,215 @@ def cpu_baseline(cfg_id, mode):
                       % (frames, nb, bs, cfg_id, "fwd+bwd+step" if mode == "train" else "fwd", dt)}
 
 
+# ------------------------------------------------------------------------------------------ extras (N = 1)
+
+def _time_loop(fn, warmup, iters):
+    """seconds per call: `iters` calls between two device synchronisations (host clock, like the headline)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def backbone_work(core, bd):
+    """Algorithmic bytes / FLOPs of voxelise + MeanVFE, the 8 rule tables, the 12 sparse convolutions and
+    the densification of one forward, from the rule tables the forward left in `bd`; t_roof = sum over kernels of
+    max(bytes / HBM peak, FLOPs / fp32-MFMA peak)."""
+    import spx
+    book = bd["encoded_spconv_tensor"].indice_dict
+    npts, c = bd["points"].shape[0], bd["voxel_features"].shape[1]
+    nvox = bd["voxel_features"].shape[0]
+    items = [("voxelize+meanvfe", 4.0 * npts * c + 4.0 * nvox * (c + 4), 0.0)]
+    seen = set()
+    for _name, m in core.backbone_3d.named_modules():
+        if not isinstance(m, spx.conv.SparseConvolution):
+            continue
+        rb = book[m.indice_key]
+        K = rb.kvol
+        if m.indice_key not in seen:
+            seen.add(m.indice_key)
+            items.append(("rulebook " + m.indice_key, rb.n_in * 16.0 + K * rb.n_out * 4.0 + (0.0 if rb.subm else rb.n_out * 16.0), 0.0))
+        P = int((rb.pair[:, :rb.n_out] >= 0).sum().item())
+        items.append(("conv %d->%d %s" % (m.in_channels, m.out_channels, m.indice_key),
+                      4.0 * (rb.n_in * m.in_channels + rb.n_out * m.out_channels + K * m.in_channels * m.out_channels + K * rb.n_out),
+                      2.0 * P * m.in_channels * m.out_channels))
+    enc = bd["encoded_spconv_tensor"]
+    cells = bd["batch_size"] * int(np.prod(enc.spatial_shape))
+    cd = enc.features.shape[1]
+    items.append(("densify", 4.0 * (enc.features.shape[0] * cd + cd * cells), 0.0))
+    t_roof = sum(max(b / HBM_PEAK, f / MFMA_F32_PEAK) for _n, b, f in items)
+    t_hbm = sum(b / HBM_PEAK for _n, b, f in items)
+    t_mfma = sum(f / MFMA_F32_PEAK for _n, b, f in items)
+    return dict(bytes=sum(b for _n, b, _f in items), flops=sum(f for _n, _b, f in items), t_roof=t_roof,
+                bound="mfma" if t_mfma > t_hbm else "hbm")
+
+
+def rulebook_rates(points, geom, batch, max_voxels, iters=30):
+    """Mvoxels/s (input voxels per second) of the 4 submanifold and the 4 strided rule tables of
+    VoxelBackBone8x on one batch, each build timed with HIP events at static capacity (no host read in the timed loop)."""
+    from pcdet_amd.datasets import synthetic
+    from spx import ops
+    vox = ops.voxelize(points, geom["point_cloud_range"], geom["voxel_size"], 5, max_voxels, batch_size=batch, batch_col=0,
+                       xyz_col=1, feat_col=1, want_voxels=False)
+    gs = synthetic.grid_size_of(geom)
+    idx, shape = vox["coords"], [int(gs[2]) + 1, int(gs[1]), int(gs[0])]
+    strided = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
+               ((3, 1, 1), (2, 1, 1), (0, 0, 0))]
+    out = {"subm": [], "strided": []}
+
+    def ev_time(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / iters
+
+    for k, s, p in strided:
+        n = idx.shape[0]
+        t = ev_time(lambda: ops.subm_rulebook(idx, batch, shape, (3, 3, 3)))
+        out["subm"].append((n, t))
+        rb = ops.conv_rulebook(idx, batch, shape, k, s, p)
+        t = ev_time(lambda: ops.conv_rulebook(idx, batch, shape, k, s, p, sync=False))
+        out["strided"].append((n, t))
+        idx, shape = rb.out_indices, rb.out_shape
+    res = {}
+    for kind, rows in out.items():
+        res[kind] = round(sum(n for n, _t in rows) / sum(t for _n, t in rows) / 1e6, 1)
+        res[kind + "_tables"] = [{"n_in": n, "us": round(t * 1e6, 1), "mvoxels_s": round(n / t / 1e6, 1)} for n, t in rows]
+    return res
+
+
+def extras(core, batches, batch, device, args):
+    """Forward-only, backbone-only, rule-table and Waymo figures (N = 1), each timed in this process after the headline."""
+    from pcdet_amd.datasets import synthetic
+    from pcdet_amd.models.inference import GraphedDetector
+    out = {}
+
+    def guard(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:                       # an extra must never take the headline down with it
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    core.eval()
+    pts = batches[0]["points"]
+
+    def fwd_modules(mods, points, bsz):
+        bd = {"points": points, "batch_size": bsz}
+        with torch.no_grad():
+            for m in mods:
+                bd = m(bd)
+        return bd
+
+    def forward():
+        t_e = _time_loop(lambda: fwd_modules(core.module_list, pts, batch), 5, 30)
+        runner = GraphedDetector(core, batch, int(pts.shape[0] * 1.05) + 64)
+        t_g = _time_loop(lambda: runner(pts), 5, 50)
+        return {"workload": "cfg 2 full detector forward (eval, f32), batch %d" % batch,
+                "eager_frames_s": round(batch / t_e, 1), "eager_ms": round(t_e * 1e3, 3),
+                "hipgraph_frames_s": round(batch / t_g, 1), "hipgraph_ms": round(t_g * 1e3, 3),
+                "overflow": {k: list(v) for k, v in runner.overflowed().items()}}
+
+    def backbone_forward():
+        mods = core.module_list[:3]                  # MeanVFE (+ voxeliser), VoxelBackBone8x, HeightCompression
+        bd = fwd_modules(mods, pts, batch)
+        work = backbone_work(core, bd)
+        t_e = _time_loop(lambda: fwd_modules(mods, pts, batch), 5, 50)
+        runner = GraphedDetector(core, batch, int(pts.shape[0] * 1.05) + 64, n_modules=3)
+        t_g = _time_loop(lambda: runner(pts), 5, 100)
+        best = min(t_e, t_g)
+        return {"workload": "cfg 2 voxelise + MeanVFE + VoxelBackBone8x + densify (eval, BN folded, f32), batch %d" % batch,
+                "eager_frames_s": round(batch / t_e, 1), "eager_ms": round(t_e * 1e3, 3),
+                "hipgraph_frames_s": round(batch / t_g, 1), "hipgraph_ms": round(t_g * 1e3, 3),
+                "roofline": {"bound": work["bound"], "t_roof_us": round(work["t_roof"] * 1e6, 2),
+                             "t_measured_us": round(best * 1e6, 2), "frac": round(work["t_roof"] / best, 4),
+                             "algorithmic_bytes": work["bytes"], "algorithmic_flops": work["flops"],
+                             "achieved_GB_s": round(work["bytes"] / best / 1e9, 1),
+                             "achieved_TFLOP_s": round(work["flops"] / best / 1e12, 2)}}
+
+    def rulebooks():
+        spec = synthetic.CONFIGS[2]
+        r = {"cfg2": rulebook_rates(pts, spec["geom"], batch, spec["geom"]["max_voxels"]["train"])}
+        b5 = synthetic.make_batch(5, 1)
+        p5 = torch.from_numpy(b5["points"]).to(device)
+        r["cfg5"] = rulebook_rates(p5, synthetic.CONFIGS[5]["geom"], 1, synthetic.CONFIGS[5]["max_voxels"])
+        return r
+
+    def waymo(cfg_id, mode, steps, warmup):
+        bsz = synthetic.CONFIGS[cfg_id]["batch"]
+        cfg, ds, model, opt, sched = build(cfg_id, device, "f32")
+        model.train(mode == "train")
+        bts = make_batches(ds, cfg_id, bsz, 0, device, n=2 if mode == "train" else 1)
+        st = Step(model, opt, sched, cfg.OPTIMIZATION.GRAD_NORM_CLIP, mode, "f32")
+        i = [0]
+
+        def one():
+            st(bts[i[0] % len(bts)])
+            i[0] += 1
+        t = _time_loop(one, warmup, steps)
+        spec = synthetic.CONFIGS[cfg_id]
+        return {"workload": "BASELINE configs[%d]: Waymo-shaped, %d pts / %d voxels per frame, batch %d, full SECOND detector %s"
+                            % (cfg_id - 1, spec["n_points"], spec["n_active"], bsz,
+                               "fwd+bwd+AdamW step" if mode == "train" else "forward"),
+                "frames_s": round(bsz / t, 2), "ms_per_step": round(t * 1e3, 3), "steps": steps, "warmup": warmup}
+
+    guard("forward", forward)
+    guard("backbone_forward", backbone_forward)
+    guard("rulebook_mvoxels_s", rulebooks)
+    torch.cuda.empty_cache()
+    guard("cfg3_fwd_bwd", lambda: waymo(3, "train", 10, 3))
+    torch.cuda.empty_cache()
+    guard("cfg5_forward", lambda: waymo(5, "fwd", 20, 5))
+    core.train()
+    return out
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as children (one process per GPU, RCCL rendezvous on
+    127.0.0.1) from a parent that never initialises the GPU — torch.cuda.device_count() does not — and hand their exit
+    code on.  Reference launch: tools/scripts/dist_train.sh:17 (torch.distributed.launch --nproc_per_node=N)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the sparse hot path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+        world = dist.get_world_size()        # what RCCL actually joined
+        if world != args.gpus:
+            sys.stderr.write("bench.py: %d ranks joined, --gpus %d\n" % (world, args.gpus))
+            sys.exit(2)
     from pcdet_amd.datasets import synthetic
     global DENSE_LAYOUT
     DENSE_LAYOUT = args.dense_layout
@@ -371,8 +579,10 @@ def main():
     cfg, ds, model, optimizer, sched = build(args.cfg, device, args.dense_dtype)
     model.train(args.mode == "train")
     if world > 1 and args.mode == "train":
+        # broadcast_buffers stays at DDP's default (True), as in the reference (tools/train.py:154-155): BatchNorm running
+        # statistics are rank 0's on every rank
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=8,
-                                                          gradient_as_bucket_view=True, broadcast_buffers=False)
+                                                          gradient_as_bucket_view=True)
     batches = make_batches(ds, args.cfg, batch, rank, device)
     step = Step(model, optimizer, sched, cfg.OPTIMIZATION.GRAD_NORM_CLIP, args.mode, args.dense_dtype)
 
@@ -433,6 +643,9 @@ def main():
                                      % (k, v["ms_per_step"], v["launches_per_step"], v["flops"] / n_inst / 1e9,
                                         v["bytes"] / n_inst / 1e6, v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                         v["bytes"] / (v["ms"] * 1e-3) / 1e9))
+    if rank == 0 and world == 1 and not args.no_extras and args.mode == "train" and args.cfg == 2:
+        core = model.module if hasattr(model, "module") else model
+        line["extras"] = extras(core, batches, batch, device, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.cfg, args.mode)
     if rank == 0:

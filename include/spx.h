@@ -42,6 +42,14 @@ extern "C" {
 #define SPX_ERR_UNSUPPORTED (-3)  /* channel count / mode this build has no kernel for                     */
 #define SPX_ERR_LAUNCH (-4)       /* hipGetLastError() != hipSuccess after a launch                        */
 #define SPX_ERR_TOO_LARGE (-5)    /* rows >= 2^31 or grid cells >= 2^40                                    */
+#define SPX_ERR_TABLE_FULL (-6)   /* DEVICE-side: a hash probe sequence found no free slot (stale workspace declared
+                                     pre-cleared); reported through a d_status word, see spx_read_status()  */
+
+/* flags of the entry points that keep a hash table in their workspace (spx_voxelize, spx_subm_rulebook) */
+#define SPX_WS_PRECLEARED 1 /* the caller has already initialised the workspace (hash keys = 0xFF bytes, values / point
+                               slots = 0x7F bytes, e.g. by one bulk fill for several calls): the library skips its own
+                               clearing launches.  A workspace that is NOT clean makes the kernels drop the rows they cannot
+                               place and raise SPX_ERR_TABLE_FULL in d_status; every probe loop is bounded by the slot count */
 
 #define SPX_MAX_KVOL 32 /* largest kernel volume kz*ky*kx supported (27 = 3x3x3 is the reference's max) */
 
@@ -51,6 +59,12 @@ typedef void *spx_stream_t;
 const char *spx_strerror(int code);
 /* Returns SPX_ABI_VERSION of the loaded library. */
 int spx_abi_version(void);
+
+/* Device status word.  Errors that only a kernel can detect (SPX_ERR_TABLE_FULL) are written with atomicMin into a
+ * caller-owned device int32 (`d_status`, nullable, initialised to 0 by the caller, sticky across calls).
+ * spx_read_status copies it to the host — the ONE entry point that synchronises `stream` — and returns it (0 or a negative
+ * SPX_ERR_* code).  A caller that reads a row count back anyway can fetch the word with the same copy instead. */
+int spx_read_status(const int32_t *d_status, spx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 1. Hard voxelisation (+ fused MeanVFE)
@@ -78,13 +92,14 @@ int spx_abi_version(void);
  *    mean       device [cap, c] fp32 = sum over kept points / max(num,1)  (NULL to skip)
  *    d_num_voxels device int64[1]: total voxels M written (rows [0,M) of every output are valid)
  *    cap        rows available in the outputs; must be >= min(n_points, batch*max_voxels)
+ *    flags      0 or SPX_WS_PRECLEARED;  d_status: device status word (nullable), see spx_read_status()
  * ---------------------------------------------------------------------------------------------- */
 size_t spx_voxelize_ws_bytes(int64_t n_points, int batch, int max_points);
 int spx_voxelize(const float *points, int64_t n_points, int point_stride, int xyz_col, int feat_col, int c,
                  int batch_col, int batch, const float *range, const float *vsize, const int32_t *grid,
                  int max_points, int max_voxels, float *voxels, int32_t *coords, int32_t *num_points,
-                 float *mean, int64_t *d_num_voxels, int64_t cap, void *ws, size_t ws_bytes,
-                 spx_stream_t stream);
+                 float *mean, int64_t *d_num_voxels, int64_t cap, int flags, int32_t *d_status, void *ws,
+                 size_t ws_bytes, spx_stream_t stream);
 
 /* Stand-alone MeanVFE for voxels produced elsewhere (e.g. by CPU dataloader workers):
  * out[v,:] = sum_t voxels[v,t,:] / max(num[v],1); replaces mean_vfe.py:26-29. */
@@ -120,11 +135,12 @@ int spx_dynamic_voxelize(const float *points, int64_t n_points, int stride, int 
  *    element, or -1;  k = (kz*KH + ky)*KW + kx.   Output rows == input rows (same order).
  *    The backward (dgrad) table of a submanifold conv is the same table read at K-1-k.
  *    cnt    device int32[K]: number of valid pairs per offset (may be NULL).
+ *    flags  0 or SPX_WS_PRECLEARED;  d_status: device status word (nullable), see spx_read_status().
  * ---------------------------------------------------------------------------------------------- */
 size_t spx_subm_rulebook_ws_bytes(int64_t n);
 int spx_subm_rulebook(const int32_t *idx, int64_t n, const int64_t *d_n, int batch, const int32_t *shape,
                       const int32_t *ksize, const int32_t *dil, int32_t *pair, int64_t pair_ld, int32_t *cnt,
-                      void *ws, size_t ws_bytes, spx_stream_t stream);
+                      int flags, int32_t *d_status, void *ws, size_t ws_bytes, spx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 3. Regular (strided) sparse-convolution rulebook

@@ -26,7 +26,7 @@ def _np(t):
 
 
 def voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels, batch_size=1, batch_col=-1, xyz_col=0,
-             feat_col=0, num_features=None, want_voxels=True, want_mean=True, sync=True):
+             feat_col=0, num_features=None, want_voxels=True, want_mean=True, sync=True, **_kw):
     pts = np.ascontiguousarray(_np(points), np.float32)
     c = (pts.shape[1] - feat_col) if num_features is None else int(num_features)
     vs, cs, ns = [], [], []
@@ -54,7 +54,7 @@ def _rulebook_cls():
     return Rulebook
 
 
-def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None):
+def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None, **_kw):
     pair, cnt = orc.subm_rulebook(_np(indices), spatial_shape, ksize, dilation)
     n = indices.shape[0]
     pair_t = torch.from_numpy(np.ascontiguousarray(pair)) if n else torch.zeros((pair.shape[0], 1), dtype=torch.int32)

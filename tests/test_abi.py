@@ -27,7 +27,7 @@ def test_abi_version_and_strerror():
     lib = _lib.load()
     assert lib.spx_abi_version() == _lib.SPX_ABI_VERSION
     assert lib.spx_strerror(0) == b"ok"
-    for code in (-1, -2, -3, -4, -5):
+    for code in (-1, -2, -3, -4, -5, -6):
         assert len(lib.spx_strerror(code)) > 4
     assert b"unknown" in lib.spx_strerror(-99)
 
@@ -37,8 +37,8 @@ def test_argument_validation_without_gpu():
     from spx import _lib
     lib = _lib.load()
     i3 = _lib.i3
-    assert lib.spx_subm_rulebook(None, 10, None, 1, i3([1, 1, 1]), i3([3, 3, 3]), i3([1, 1, 1]), None, 10, None, None,
-                                 0, None) == -1
+    assert lib.spx_subm_rulebook(None, 10, None, 1, i3([1, 1, 1]), i3([3, 3, 3]), i3([1, 1, 1]), None, 10, None, 0, None,
+                                 None, 0, None) == -1
     assert lib.spx_pack_weight(None, 16, 27, 16, 0, None, None) == -1
     assert lib.spx_conv_out_cap(1000, 2, i3([21, 800, 704]), i3([3, 3, 3]), i3([2, 2, 2])) == 8000
     assert lib.spx_conv_out_cap(1000, 1, i3([2, 3, 4]), i3([3, 3, 3]), i3([1, 1, 1])) == 24

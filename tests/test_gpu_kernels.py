@@ -782,3 +782,48 @@ def test_fused_bn_relu_cat_matches_torch():
     ym2.backward(wide[:, 3:])
     for a, b in zip(xm2, xm):
         assert torch.equal(a.grad, b.grad)
+
+
+# ------------------------------------------------------------------------------------------ bounded hash probes
+
+def test_dirty_precleared_workspace_reports_table_full_instead_of_hanging(orc):
+    """SPX_WS_PRECLEARED on a workspace that is NOT clean (every hash key slot holds a foreign key): the voxeliser and the
+    submanifold rulebook must come back with SPX_ERR_TABLE_FULL in the status word — every probe loop is bounded by the
+    slot count (round 1 recorded an endless CAS probe on a stale workspace) — and the next ordinary call must be exact."""
+    from spx import _lib, ops
+    from pcdet_amd.datasets import synthetic as syn
+    dev = _dev()
+    geom = syn.KITTI
+    frame = syn.make_frame(1, 0)
+    pts = torch.from_numpy(frame["points"][:4096]).to(dev)
+    lib = _lib.load()
+    wsb = max(lib.spx_voxelize_ws_bytes(pts.shape[0], 1, 5), lib.spx_subm_rulebook_ws_bytes(4096))
+    ws = ops.workspace(dev, wsb)
+    ws.view(torch.int32).fill_(0x01010101)          # no slot is EMPTY (0xFF..), no key of this frame matches
+    with pytest.raises(_lib.SpxError, match="hash table full"):
+        ops.voxelize(pts, geom["point_cloud_range"], geom["voxel_size"], 5, 16000, ws_precleared=True)
+    vox = ops.voxelize(pts, geom["point_cloud_range"], geom["voxel_size"], 5, 16000)      # library clears: exact again
+    v_o, c_o, _n = orc.voxelize(frame["points"][:4096], geom["point_cloud_range"], geom["voxel_size"], 5, 16000)
+    assert np.array_equal(vox["coords"][:, 1:].cpu().numpy(), c_o)
+    assert np.array_equal(vox["voxels"].cpu().numpy(), v_o)
+
+    idx = vox["coords"]
+    shape = [41, 1600, 1408]
+    ops.check_status(dev)                           # clean so far
+    ops.workspace(dev, wsb).view(torch.int32).fill_(0x01010101)
+    rb = ops.subm_rulebook(idx, 1, shape, (3, 3, 3), ws_precleared=True)
+    torch.cuda.synchronize()                        # returns: bounded probes
+    with pytest.raises(_lib.SpxError, match="hash table full"):
+        ops.check_status(dev)
+    ops.check_status(dev)                           # the word was reset by the failed check
+    assert int((rb.pair >= 0).sum()) == 0           # nothing was found in the foreign table
+    rb = ops.subm_rulebook(idx, 1, shape, (3, 3, 3))
+    pair_o, _ = orc.subm_rulebook(idx.cpu().numpy(), shape)
+    assert np.array_equal(rb.pair[:, :rb.n_out].cpu().numpy(), pair_o)
+    ops.check_status(dev)
+    assert lib.spx_read_status(ctypes_ptr(ops.status_word(dev)), None) == 0
+
+
+def ctypes_ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())

@@ -117,3 +117,30 @@ def test_data_processor_host_steps():
     test_dp = DataProcessor(steps, pcr, training=False, num_point_features=4)
     out2 = test_dp.forward({"points": pts.copy(), "gt_boxes": boxes.copy(), "use_lead_xyz": True})
     assert np.array_equal(out2["points"], pts[[0, 2, 4]]) and out2["gt_boxes"].shape[0] == 3     # no shuffle, boxes kept
+
+
+def test_bench_launcher_refuses_what_it_cannot_run():
+    """`bench.py --gpus N` must start N ranks itself or fail loudly — never time one rank and call it N (round-1 bug: the
+    flag was parsed and ignored).  No GPU here, so both refusals are exercised: fewer GPUs than ranks, and a torchrun
+    environment whose WORLD_SIZE disagrees with --gpus.  Neither path touches the GPU."""
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "64", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "only" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bn_momentum_none_is_not_fused():
+    """nn.BatchNorm with momentum=None keeps a cumulative average; the fused kernels take a fixed factor, so such a module
+    must stay on the torch path."""
+    import torch
+    from spx import functional as F_
+    bn = torch.nn.BatchNorm1d(16, momentum=None)
+    assert not F_.bn_momentum_ok(bn) and F_.bn_momentum_ok(torch.nn.BatchNorm1d(16, momentum=0.01))
+    x = torch.randn(8, 16)
+    assert not F_.bn_train_fusable(bn, x)

@@ -22,8 +22,6 @@
 //
 // Serves the autograd of reference call sites spconv_backbone.py:86-121, triggered by loss.backward()
 // at tools/train_utils/train_utils.py:53.
-#include <stdlib.h>
-
 #include "spx_common.h"
 
 #ifdef SPX_WG_DIAG
@@ -50,10 +48,10 @@ constexpr int kBurst = SPX_WG_BURST;  // K-steps whose loads are in flight toget
 // traffic (<= 32 MiB) and by at least one full iteration (64*kGroups rows) per block
 static inline int wgrad_splits(int64_t n, int cin, int cout, int kvol) {
   int64_t s = n / (64 * kGroups);
-  static const int slab_mb = getenv("SPX_WGRAD_SLAB_MB") ? atoi(getenv("SPX_WGRAD_SLAB_MB")) : 32;   // dev knob
+  constexpr int slab_mb = 32;
   int64_t by_slab = (int64_t(slab_mb) << 20) / ((int64_t)kvol * cin * cout * 4);
   if (s > by_slab) s = by_slab;
-  static const int max_blocks = getenv("SPX_WGRAD_BLOCKS") ? atoi(getenv("SPX_WGRAD_BLOCKS")) : 2048;   // dev knob
+  constexpr int max_blocks = 2048;
   int64_t by_blocks = max_blocks / kvol;          // two one-wave blocks per SIMD keep its MFMA pipe busy; more only lengthens the reduce
   if (by_blocks < 8) by_blocks = 8;
   if (s > by_blocks) s = by_blocks;

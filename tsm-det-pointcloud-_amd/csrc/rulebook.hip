@@ -24,7 +24,16 @@ struct HashTable {
   uint64_t* keys;
   int32_t* vals;
   int log2size;
+  int32_t* status;   // device status word (nullable): receives SPX_ERR_TABLE_FULL when a probe sequence finds no end
 };
+
+// Every probe sequence is bounded by the slot count.  A table sized by hash_slots() and cleared by the library always has
+// >= 50 % empty slots, so the bound is only ever reached on a workspace the caller declared pre-cleared
+// (SPX_WS_PRECLEARED) but which holds stale keys: the row is then dropped and the status word says so, instead of a wave
+// that spins for ever.
+__device__ __forceinline__ void table_full(int32_t* status) {
+  if (status) atomicMin(status, (int32_t)SPX_ERR_TABLE_FULL);
+}
 
 static inline int64_t hash_slots(int64_t n) {
   int64_t s = 1024;
@@ -48,7 +57,7 @@ __global__ void k_hash_insert(const int32_t* __restrict__ idx, int64_t n, const 
   uint64_t key = (uint64_t)spx_lin_key(c.x, c.y, c.z, c.w, shape);
   uint64_t mask = (1ull << t.log2size) - 1;
   uint64_t slot = spx_hash64(key) >> (64 - t.log2size);
-  for (;;) {
+  for (uint64_t probe = 0; probe <= mask; ++probe) {
     unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.keys[slot]), kEmpty, key);
     if (old == kEmpty || old == key) {
       atomicMin(&t.vals[slot], (int32_t)i);  // duplicates: smallest row wins (deterministic)
@@ -56,17 +65,20 @@ __global__ void k_hash_insert(const int32_t* __restrict__ idx, int64_t n, const 
     }
     slot = (slot + 1) & mask;
   }
+  table_full(t.status);
 }
 
 __device__ __forceinline__ int32_t hash_find(const HashTable& t, uint64_t key) {
   uint64_t mask = (1ull << t.log2size) - 1;
   uint64_t slot = spx_hash64(key) >> (64 - t.log2size);
-  for (;;) {
+  for (uint64_t probe = 0; probe <= mask; ++probe) {
     uint64_t k = t.keys[slot];
     if (k == key) return t.vals[slot];
     if (k == kEmpty) return -1;
     slot = (slot + 1) & mask;
   }
+  table_full(t.status);
+  return -1;
 }
 
 // grid (ceil(n/256), K): one probe per (row, offset); rows of one offset are contiguous -> coalesced stores
@@ -292,8 +304,10 @@ extern "C" size_t spx_subm_rulebook_ws_bytes(int64_t n) {
 
 extern "C" int spx_subm_rulebook(const int32_t* idx, int64_t n, const int64_t* d_n, int batch, const int32_t* shape,
                                  const int32_t* ksize, const int32_t* dil, int32_t* pair, int64_t pair_ld,
-                                 int32_t* cnt, void* ws, size_t ws_bytes, spx_stream_t stream) {
-  if ((!idx && n > 0) || !shape || !ksize || !dil || (!pair && n > 0) || n < 0 || batch <= 0 || pair_ld < n)
+                                 int32_t* cnt, int flags, int32_t* d_status, void* ws, size_t ws_bytes,
+                                 spx_stream_t stream) {
+  if ((!idx && n > 0) || !shape || !ksize || !dil || (!pair && n > 0) || n < 0 || batch <= 0 || pair_ld < n ||
+      (flags & ~SPX_WS_PRECLEARED))
     return SPX_ERR_INVALID_ARG;
   int K = ksize[0] * ksize[1] * ksize[2];
   if (K <= 0 || K > SPX_MAX_KVOL) return SPX_ERR_INVALID_ARG;
@@ -307,8 +321,11 @@ extern "C" int spx_subm_rulebook(const int32_t* idx, int64_t n, const int64_t* d
   t.keys = reinterpret_cast<uint64_t*>(ws);
   t.vals = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + spx_align((size_t)slots * 8));
   t.log2size = ilog2(slots);
-  spx_fill_async(t.keys, 0xFF, (size_t)slots * 8, s);
-  spx_fill_async(t.vals, 0x7F, (size_t)slots * 4, s);
+  t.status = d_status;
+  if (!(flags & SPX_WS_PRECLEARED)) {
+    spx_fill_async(t.keys, 0xFF, (size_t)slots * 8, s);
+    spx_fill_async(t.vals, 0x7F, (size_t)slots * 4, s);
+  }
   unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_hash_insert, dim3(nb), dim3(kBlock), 0, s, idx, n, d_n, batch, spx_i3(shape), t);
   hipLaunchKernelGGL(k_subm_probe, dim3(nb, K), dim3(kBlock), 0, s, idx, n, d_n, spx_i3(shape), spx_i3(ksize),

@@ -86,7 +86,7 @@ __device__ __forceinline__ bool point_cell(const float* pt, int xyz_col, const V
 }
 
 __global__ void k_vox_insert(const float* __restrict__ pts, int64_t n, int stride, int xyz_col, int batch_col,
-                             int batch, VoxGeom g, int T, VoxWs w) {
+                             int batch, VoxGeom g, int T, VoxWs w, int32_t* status) {
   int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
   int cx, cy, cz;
@@ -99,10 +99,22 @@ __global__ void k_vox_insert(const float* __restrict__ pts, int64_t n, int strid
   uint64_t key = ((((uint64_t)b * g.grid[2] + cz) * g.grid[1] + cy) * g.grid[0]) + cx;
   uint64_t mask = (uint64_t)w.slots - 1;
   uint64_t slot = spx_hash64(key) >> (64 - w.log2size);
-  for (;;) {
+  // The probe sequence is bounded by the slot count: the table is sized >= 2n and cleared by the library, so the bound is
+  // only reached on a workspace the caller declared pre-cleared (SPX_WS_PRECLEARED) that holds stale keys.  The point is
+  // then dropped and the status word receives SPX_ERR_TABLE_FULL — not a wave that spins for ever.
+  bool placed = false;
+  for (uint64_t probe = 0; probe <= mask; ++probe) {
     unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&w.keys[slot]), kEmpty, key);
-    if (old == kEmpty || old == key) break;
+    if (old == kEmpty || old == key) {
+      placed = true;
+      break;
+    }
     slot = (slot + 1) & mask;
+  }
+  if (!placed) {
+    w.pt_slot[p] = -1;
+    if (status) atomicMin(status, (int32_t)SPX_ERR_TABLE_FULL);
+    return;
   }
   w.pt_slot[p] = (int32_t)slot;
   int32_t carry = (int32_t)p;
@@ -243,12 +255,12 @@ extern "C" size_t spx_voxelize_ws_bytes(int64_t n_points, int batch, int max_poi
 extern "C" int spx_voxelize(const float* points, int64_t n_points, int point_stride, int xyz_col, int feat_col, int c,
                             int batch_col, int batch, const float* range, const float* vsize, const int32_t* grid,
                             int max_points, int max_voxels, float* voxels, int32_t* coords, int32_t* num_points,
-                            float* mean, int64_t* d_num_voxels, int64_t cap, void* ws, size_t ws_bytes,
-                            spx_stream_t stream) {
+                            float* mean, int64_t* d_num_voxels, int64_t cap, int flags, int32_t* d_status, void* ws,
+                            size_t ws_bytes, spx_stream_t stream) {
   if ((!points && n_points > 0) || !range || !vsize || !grid || !coords || !num_points || !d_num_voxels || n_points < 0 ||
       point_stride <= 0 || c <= 0 || xyz_col < 0 || feat_col < 0 || xyz_col + 3 > point_stride ||
       feat_col + c > point_stride || batch_col >= point_stride || batch <= 0 || max_points <= 0 ||
-      max_points > 64 || max_voxels <= 0 || cap <= 0)
+      max_points > 64 || max_voxels <= 0 || cap <= 0 || (flags & ~SPX_WS_PRECLEARED))
     return SPX_ERR_INVALID_ARG;
   if (n_points >= (int64_t)kNoPoint) return SPX_ERR_TOO_LARGE;
   if ((int64_t)batch * grid[0] * grid[1] * grid[2] >= (int64_t(1) << 62)) return SPX_ERR_TOO_LARGE;
@@ -268,12 +280,14 @@ extern "C" int spx_voxelize(const float* points, int64_t n_points, int point_str
     g.vs[j] = vsize[j];
     g.grid[j] = grid[j];
   }
-  spx_fill_async(w.keys, 0xFF, (size_t)w.slots * 8, s);
-  spx_fill_async(w.top, 0x7F, (size_t)w.slots * max_points * 4, s);
+  if (!(flags & SPX_WS_PRECLEARED)) {
+    spx_fill_async(w.keys, 0xFF, (size_t)w.slots * 8, s);
+    spx_fill_async(w.top, 0x7F, (size_t)w.slots * max_points * 4, s);
+  }
   spx_fill_async(w.first, 0xFF, (size_t)(batch + 1) * 4, s);
   unsigned nb = (unsigned)w.nblk;
   hipLaunchKernelGGL(k_vox_insert, dim3(nb), dim3(kBlock), 0, s, points, n_points, point_stride, xyz_col, batch_col,
-                     batch, g, max_points, w);
+                     batch, g, max_points, w, d_status);
   hipLaunchKernelGGL(k_vox_blocksum, dim3(nb), dim3(kBlock), 0, s, n_points, max_points, w);
   hipLaunchKernelGGL(k_vox_scan_top, dim3(1), dim3(kBlock), 0, s, w);
   hipLaunchKernelGGL(k_vox_rank, dim3(nb), dim3(kBlock), 0, s, points, n_points, point_stride, batch_col, batch,

@@ -35,6 +35,9 @@ CONFIGS = {
     3: dict(geom=WAYMO, n_points=180000, n_active=80000, batch=2),
     4: dict(geom=WAYMO, n_points=180000, n_active=80000, batch=2),
     5: dict(geom=WAYMO, n_points=600000, n_active=300000, batch=1, max_voxels=400000),
+    # not a BASELINE config: the Waymo geometry (full 1504 x 1504 x 40 grid, C = 5, Waymo yaml) at a voxel count the CPU
+    # oracle affords, for detector-level parity tests of the Waymo model
+    6: dict(geom=WAYMO, n_points=18000, n_active=8000, batch=2, n_obj=12),
 }
 
 

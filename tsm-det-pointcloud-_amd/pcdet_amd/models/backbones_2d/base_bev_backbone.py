@@ -35,7 +35,7 @@ def _run_block(seq, x, start=0):
             i += 2
             continue
         if (isinstance(m, nn.BatchNorm2d) and isinstance(nxt, nn.ReLU) and m.training and m.affine
-                and m.track_running_stats and x.is_cuda and x.dtype == torch.float32
+                and m.track_running_stats and m.momentum is not None and x.is_cuda and x.dtype == torch.float32
                 and x.numel() >= _FUSED_BN_MIN_ELEMS and 1024 % x.shape[1] == 0 and x.shape[1] % 4 == 0
                 and x.is_contiguous(memory_format=torch.channels_last)):
             b, c, h, w = x.shape
@@ -155,7 +155,7 @@ class BaseBEVBackbone(nn.Module):
         for d in self.deblocks:
             mods = list(d)
             if not (len(mods) == 3 and isinstance(mods[1], nn.BatchNorm2d) and isinstance(mods[2], nn.ReLU)
-                    and mods[1].training and mods[1].affine and mods[1].track_running_stats
+                    and mods[1].training and mods[1].affine and mods[1].track_running_stats and mods[1].momentum is not None
                     and 1024 % mods[1].num_features == 0 and mods[1].num_features % 4 == 0):
                 return False
         return True

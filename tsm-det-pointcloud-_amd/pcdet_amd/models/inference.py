@@ -18,8 +18,10 @@ DEFAULT_LEVEL_FACTORS = {'spconv2': 2.0, 'spconv3': 2.0, 'spconv4': 1.0, 'spconv
 
 
 class GraphedDetector(object):
-    def __init__(self, model, batch_size, max_points, level_factors=None, warmup=2):
+    def __init__(self, model, batch_size, max_points, level_factors=None, warmup=2, n_modules=None):
+        """n_modules: run only the first n modules of model.module_list (3 = voxelise + VFE, 3-D backbone, BEV collapse)."""
         self.model = model.eval()
+        self.modules = list(model.module_list) if n_modules is None else list(model.module_list)[:int(n_modules)]
         self.batch_size = int(batch_size)
         vfe = model.vfe
         self.device = next(model.parameters()).device
@@ -52,15 +54,16 @@ class GraphedDetector(object):
     def _forward(self):
         bd = {'points': self.points, 'batch_size': self.batch_size, 'static_caps': self.static_caps}
         with torch.no_grad():
-            for m in self.model.module_list:
+            for m in self.modules:
                 bd = m(bd)
         ms = bd['multi_scale_3d_features']
-        return {'batch_cls_preds': bd['batch_cls_preds'], 'batch_box_preds': bd['batch_box_preds'],
-                'cls_preds_normalized': bd['cls_preds_normalized'], 'batch_size': self.batch_size,
+        out = {k: bd[k] for k in ('batch_cls_preds', 'batch_box_preds', 'cls_preds_normalized') if k in bd}
+        out.update({'batch_size': self.batch_size,
                 'spatial_features': bd['spatial_features'],
                 'counts': {'voxels': bd['voxel_num_valid'], 'spconv2': ms['x_conv2'].n_valid,
                            'spconv3': ms['x_conv3'].n_valid, 'spconv4': ms['x_conv4'].n_valid,
-                           'spconv_down2': bd['encoded_spconv_tensor'].n_valid}}
+                           'spconv_down2': bd['encoded_spconv_tensor'].n_valid}})
+        return out
 
     def __call__(self, points):
         """points [N, 1+C] (frame index in column 0, frames contiguous and ascending), N <= max_points, on the GPU.

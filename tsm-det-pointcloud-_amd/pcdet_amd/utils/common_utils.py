@@ -54,6 +54,23 @@ def set_random_seed(seed):
     torch.manual_seed(seed)
 
 
+class AverageMeter(object):
+    """running value / mean of a scalar (the d_time / f_time / b_time meters of the reference's train_one_epoch,
+    tools/train_utils/train_utils.py:19-22; reference common_utils.py:283-299)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
 def get_dist_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

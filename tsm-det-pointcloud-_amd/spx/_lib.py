@@ -28,8 +28,9 @@ SIGNATURES = {
     "spx_strerror": (ctypes.c_char_p, [_int]),
     "spx_abi_version": (_int, []),
     "spx_voxelize_ws_bytes": (_sz, [_i64, _int, _int]),
+    "spx_read_status": (_int, [_vp, _vp]),
     "spx_voxelize": (_int, [_vp, _i64, _int, _int, _int, _int, _int, _int, _f32p, _f32p, _i32p, _int, _int, _vp, _vp,
-                            _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+                            _vp, _vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "spx_dynamic_voxelize_ws_bytes": (_sz, [_i64, _int, _i32p, _i64]),
     "spx_dynamic_voxelize": (_int, [_vp, _i64, _int, _int, _int, _int, _f32p, _f32p, _i32p, _int, _vp, _vp, _vp, _vp, _i64,
                                     _vp, _sz, _vp]),
@@ -38,7 +39,7 @@ SIGNATURES = {
                                        _i32p, _vp, _vp, _vp, _vp]),
     "spx_mean_vfe": (_int, [_vp, _vp, _i64, _vp, _int, _int, _vp, _vp]),
     "spx_subm_rulebook_ws_bytes": (_sz, [_i64]),
-    "spx_subm_rulebook": (_int, [_vp, _i64, _vp, _int, _i32p, _i32p, _i32p, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "spx_subm_rulebook": (_int, [_vp, _i64, _vp, _int, _i32p, _i32p, _i32p, _vp, _i64, _vp, _int, _vp, _vp, _sz, _vp]),
     "spx_conv_out_cap": (_i64, [_i64, _int, _i32p, _i32p, _i32p]),
     "spx_conv_rulebook_ws_bytes": (_sz, [_i64, _int, _i32p]),
     "spx_conv_rulebook": (_int, [_vp, _i64, _vp, _int, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _vp, _vp, _vp, _vp,

@@ -9,30 +9,36 @@ from . import ops
 
 
 def _packed(weight, mode):
-    """MFMA-ordered copy of `weight`, cached on the parameter until it is modified in place (optimizer step, load).
-    When a gradient will be needed both operand orders are produced by ONE launch at forward time and the backward pass
-    finds its half in the cache (the weights do not change in between).  While a hipGraph is being captured the pack
-    kernel is always recorded, so a replay never reads a stale copy."""
+    """MFMA-ordered copy of `weight`, cached until the parameter is modified in place (optimizer step, load).  The cache
+    lives on the BASE tensor when `weight` is a view of a parameter (the BEV entry conv re-views its Conv2d weight per
+    call; view and base share the version counter), keyed by the view's geometry.  For a weight that takes a gradient
+    both operand orders are produced by ONE launch at forward time and the backward pass finds its half in the cache (the
+    weights do not change in between) — decided on requires_grad alone: inside autograd.Function.forward grad mode is
+    always off.  While a hipGraph is being captured the pack kernel is always recorded, so a replay never reads a stale
+    copy."""
     if weight.is_cuda and torch.cuda.is_current_stream_capturing():
         return ops.pack_weight(weight, mode)
-    cache = getattr(weight, "_spx_packed", None)
+    holder = weight._base if weight._base is not None else weight
+    cache = getattr(holder, "_spx_packed", None)
     if cache is None:
         cache = {}
         try:
-            weight._spx_packed = cache
+            holder._spx_packed = cache
         except AttributeError:
             return ops.pack_weight(weight, mode)
-    key = (mode, weight.data_ptr())
+    geom = (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()))
+    key = (mode,) + geom
     hit = cache.get(key)
     if hit is not None and hit[0] == weight._version:
         return hit[1]
-    cache.clear()
-    if mode == 0 and weight.requires_grad and torch.is_grad_enabled():
+    for k in [k for k, v in cache.items() if v[0] != weight._version]:
+        del cache[k]
+    if weight.is_cuda and (weight.requires_grad or holder.requires_grad):
         both = ops.pack_weight(weight, 2)
         half = both.numel() // 2
-        cache[key] = (weight._version, both[:half])
-        cache[(1, weight.data_ptr())] = (weight._version, both[half:])
-        return both[:half]
+        cache[(0,) + geom] = (weight._version, both[:half])
+        cache[(1,) + geom] = (weight._version, both[half:])
+        return both[:half] if mode == 0 else both[half:]
     wp = ops.pack_weight(weight, mode)
     cache[key] = (weight._version, wp)
     return wp
@@ -137,7 +143,7 @@ def sparse_conv_bn_relu(feats, weight, bias, rb, bn, relu):
     """sparse_conv (not inverse) followed by `bn` in training mode and optionally ReLU, as one autograd node."""
     tables = ((rb.pair, rb.ld, rb.n_out, rb.pair, rb.ld, True) if rb.subm else
               (rb.pair, rb.ld, rb.n_out, rb.pair_bwd, rb.pair_bwd.shape[1], False))
-    mom = bn.momentum if bn.momentum is not None else 0.1
+    mom = bn.momentum          # never None here: bn_momentum_ok() gates every fused path
     return _SparseConvBNReLUFn.apply(feats, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      bn.num_batches_tracked, mom, bn.eps, relu, tables, rb, rb.d_n_out, rb.d_n_in)
 
@@ -238,25 +244,31 @@ class _BNReLUCatFn(torch.autograd.Function):
 def bn_relu_cat_train(xs, bns):
     """[relu(bn_i(x_i))] concatenated along the channel axis -> [N, sum C_i]; bns: nn.BatchNorm modules in training mode
     that libspx's kernels cover (see bn_train_fusable for the conditions on each pair)."""
-    moms = tuple(bn.momentum if bn.momentum is not None else 0.1 for bn in bns)
+    moms = tuple(bn.momentum for bn in bns)                         # callers check bn_train_fusable: never None
     epss = tuple(bn.eps for bn in bns)
     args = (tuple(xs) + tuple(bn.weight for bn in bns) + tuple(bn.bias for bn in bns) + tuple(bn.running_mean for bn in bns)
             + tuple(bn.running_var for bn in bns) + tuple(bn.num_batches_tracked for bn in bns))
     return _BNReLUCatFn.apply(moms, epss, *args)
 
 
+def bn_momentum_ok(bn):
+    """momentum=None means a CUMULATIVE moving average in torch (factor 1 / num_batches_tracked): the fused kernels take a
+    fixed factor, so such a module stays on the torch path."""
+    return bn.momentum is not None
+
+
 def bn_train_fusable(bn, f):
     """True when libspx's training-mode BatchNorm kernels cover `bn` applied to the rows of f [N, C]."""
-    return (isinstance(bn, torch.nn.BatchNorm1d) and bn.training and bn.affine and bn.track_running_stats and f.is_cuda
+    return (isinstance(bn, torch.nn.BatchNorm1d) and bn.training and bn.affine and bn.track_running_stats
+            and bn_momentum_ok(bn) and f.is_cuda
             and f.dtype == torch.float32 and f.dim() == 2 and f.shape[0] > 1 and ops.bn_relu_supported(f.shape[1]))
 
 
 def bn_relu_train(x, bn, relu, residual=None):
     """x [N, C] through `bn` (nn.BatchNorm1d in training mode, affine, tracking running stats), plus `residual` when
     given, and optionally ReLU."""
-    mom = bn.momentum if bn.momentum is not None else 0.1
     # num_batches_tracked is incremented inside the finalize kernel (one launch less per layer)
-    return _BNReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps, relu, residual,
+    return _BNReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, residual,
                            bn.num_batches_tracked)
 
 

@@ -119,7 +119,7 @@ def _train_bn_pre(conv, mods, i, x):
         return None
     bn = mods[i + 1]
     if not (isinstance(bn, nn.BatchNorm1d) and bn.training and bn.affine and bn.track_running_stats
-            and x.features.dtype == torch.float32 and ops.bn_relu_supported(conv.out_channels)
+            and F_.bn_momentum_ok(bn) and x.features.dtype == torch.float32 and ops.bn_relu_supported(conv.out_channels)
             and x.features.shape[0] > 1 and torch.is_grad_enabled()):
         return None
     relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)

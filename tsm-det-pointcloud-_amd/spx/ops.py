@@ -51,6 +51,36 @@ def workspace(device, nbytes):
     return buf
 
 
+_STATUS = {}
+
+
+def status_word(device):
+    """The sticky device status word of `device` (int32[1], include/spx.h: d_status): kernels of calls made without a host
+    read (static-capacity / graph mode) report device-side errors here; check_status() reads it."""
+    w = _STATUS.get(device.index)
+    if w is None:
+        w = _STATUS[device.index] = torch.zeros((1,), dtype=torch.int32, device=device)
+    return w
+
+
+def check_status(device):
+    """Read (one host sync) and reset the sticky status word; raises SpxError on a device-side error."""
+    w = status_word(device)
+    rc = int(w.item())
+    if rc != 0:
+        w.zero_()
+        check(rc, "device status")
+
+
+def _count_and_status(buf, what):
+    """buf: int64[2] = (row count, status word in the low 32 bits) -> count; raises on a device-side error (one sync)."""
+    cnt, st = buf.tolist()
+    st &= 0xFFFFFFFF
+    if st:
+        check(st - (1 << 32), what)
+    return int(cnt)
+
+
 def out_shape_of(in_shape, ksize, stride, pad, dil):
     return [(int(i) + 2 * int(p) - int(d) * (int(k) - 1) - 1) // int(s) + 1
             for i, k, s, p, d in zip(in_shape, ksize, stride, pad, dil)]
@@ -77,11 +107,12 @@ class Rulebook(object):
 # ------------------------------------------------------------------------------------------- voxelise
 
 def voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels, batch_size=1, batch_col=-1, xyz_col=0,
-             feat_col=0, num_features=None, want_voxels=True, want_mean=True, sync=True):
+             feat_col=0, num_features=None, want_voxels=True, want_mean=True, sync=True, ws_precleared=False):
     """GPU hard voxelisation (+ fused MeanVFE).  Returns dict(voxels, coords[M,4], num_points, mean, M).
 
     sync=True: one host sync (reads M) and exact-size views.  sync=False (static-capacity / graph mode): no sync, every
     output keeps its capacity rows and the live count is the device tensor `d_num_voxels`.
+    ws_precleared: SPX_WS_PRECLEARED — the caller filled ops.workspace() itself (see include/spx.h).
     Semantics: include/spx.h §1 / SURVEY.md §8a row a1.
     """
     _need_gpu(points)
@@ -98,16 +129,21 @@ def voxelize(points, point_cloud_range, voxel_size, max_points, max_voxels, batc
     coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     num = torch.empty((cap,), dtype=torch.int32, device=dev)
     mean = torch.empty((cap, c), dtype=torch.float32, device=dev) if want_mean else None
-    d_m = torch.zeros((1,), dtype=torch.int64, device=dev)
+    # (count, status): with a host read the call gets its own status word next to the count, one copy fetches both;
+    # without, device-side errors go to the sticky per-device word (check_status)
+    buf = torch.zeros((2,), dtype=torch.int64, device=dev)
+    d_m = buf[:1]
+    d_st = ctypes.c_void_p(buf.data_ptr() + 8) if sync else _ptr(status_word(dev))
     wsb = lib.spx_voxelize_ws_bytes(n, batch_size, max_points)
     ws = workspace(dev, wsb)
     check(lib.spx_voxelize(_ptr(points), n, stride, xyz_col, feat_col, c, batch_col, batch_size, f_arr(rng), f_arr(vs),
                            i3(grid), max_points, max_voxels, _ptr(voxels), _ptr(coords), _ptr(num), _ptr(mean),
-                           _ptr(d_m), cap, _ptr(ws), wsb, _stream(points)), "spx_voxelize")
+                           _ptr(d_m), cap, 1 if ws_precleared else 0, d_st, _ptr(ws), wsb, _stream(points)),
+          "spx_voxelize")
     if not sync:
         return dict(voxels=voxels, coords=coords, num_points=num, mean=mean, num_voxels=None, d_num_voxels=d_m,
                     grid_size=grid)
-    m = int(d_m.item())
+    m = _count_and_status(buf, "spx_voxelize")
     return dict(voxels=None if voxels is None else voxels[:m], coords=coords[:m], num_points=num[:m],
                 mean=None if mean is None else mean[:m], num_voxels=m, d_num_voxels=d_m, grid_size=grid)
 
@@ -159,8 +195,10 @@ def mean_vfe(voxels, num_points):
 
 # ------------------------------------------------------------------------------------------- rulebooks
 
-def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None):
-    """d_n: optional device int64[1] live row count (<= indices.shape[0], which is then the capacity)."""
+def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None,
+                  ws_precleared=False):
+    """d_n: optional device int64[1] live row count (<= indices.shape[0], which is then the capacity).  Device-side
+    errors (only possible with ws_precleared on a dirty workspace) go to the sticky status word: check_status()."""
     _need_gpu(indices)
     lib = _lib.load()
     indices = indices.contiguous()
@@ -174,7 +212,8 @@ def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1),
     wsb = lib.spx_subm_rulebook_ws_bytes(n)
     ws = workspace(dev, wsb)
     check(lib.spx_subm_rulebook(_ptr(indices), n, _ptr(d_n), batch_size, i3(spatial_shape), i3(ksize), i3(dilation),
-                                _ptr(pair), ld, _ptr(cnt), _ptr(ws), wsb, _stream(indices)), "spx_subm_rulebook")
+                                _ptr(pair), ld, _ptr(cnt), 1 if ws_precleared else 0, _ptr(status_word(dev)), _ptr(ws), wsb,
+                                _stream(indices)), "spx_subm_rulebook")
     rb = Rulebook(pair, ld, n, n, K, True, indices, spatial_shape, spatial_shape, cnt=cnt, ksize=list(ksize),
                   stride=[1, 1, 1], padding=[k // 2 for k in ksize], dilation=list(dilation))
     rb.d_n_in = rb.d_n_out = d_n
