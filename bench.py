@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward / backbone / rulebook / Waymo extras")
+    ap.add_argument("--dynamic", action="store_true",
+                    help="training with exact-size sparse tensors (one host read per strided rule table) instead of the "
+                         "host-sync-free static-capacity path")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     return ap.parse_args()
 
@@ -101,8 +104,9 @@ def make_batches(ds, cfg_id, batch, rank, device, n=2):
 
 
 class Step(object):
-    def __init__(self, model, optimizer, sched, clip, mode, dense_dtype):
+    def __init__(self, model, optimizer, sched, clip, mode, dense_dtype, static_caps=None):
         self.model, self.opt, self.sched, self.clip, self.mode = model, optimizer, sched, clip, mode
+        self.static_caps = static_caps       # training at static row capacities: no host read anywhere in the step
         self.dense_dtype = {"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}[dense_dtype]
         self.it = 0
         core = model.module if hasattr(model, "module") else model
@@ -130,6 +134,8 @@ class Step(object):
             return bd["batch_box_preds"]
         self.sched.step(self.it)
         self.opt.zero_grad(set_to_none=True)
+        if self.static_caps is not None:
+            bd["static_caps"] = self.static_caps
         ret, _tb, _ = self.model(bd)
         loss = ret["loss"].mean()
         loss.backward()
@@ -509,13 +515,19 @@ def extras(core, batches, batch, device, args):
         cfg, ds, model, opt, sched = build(cfg_id, device, "f32")
         model.train(mode == "train")
         bts = make_batches(ds, cfg_id, bsz, 0, device, n=2 if mode == "train" else 1)
-        st = Step(model, opt, sched, cfg.OPTIMIZATION.GRAD_NORM_CLIP, mode, "f32")
+        caps = None
+        if mode == "train" and not args.dynamic:
+            from pcdet_amd.models.inference import static_caps_for
+            caps = static_caps_for(model, bsz, max(int(b["points"].shape[0]) for b in bts), training=True)
+        st = Step(model, opt, sched, cfg.OPTIMIZATION.GRAD_NORM_CLIP, mode, "f32", static_caps=caps)
         i = [0]
 
         def one():
             st(bts[i[0] % len(bts)])
             i[0] += 1
         t = _time_loop(one, warmup, steps)
+        from spx import ops as _ops
+        _ops.check_status(device)
         spec = synthetic.CONFIGS[cfg_id]
         return {"workload": "BASELINE configs[%d]: Waymo-shaped, %d pts / %d voxels per frame, batch %d, full SECOND detector %s"
                             % (cfg_id - 1, spec["n_points"], spec["n_active"], bsz,
@@ -584,7 +596,12 @@ def main():
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=8,
                                                           gradient_as_bucket_view=True)
     batches = make_batches(ds, args.cfg, batch, rank, device)
-    step = Step(model, optimizer, sched, cfg.OPTIMIZATION.GRAD_NORM_CLIP, args.mode, args.dense_dtype)
+    caps = None
+    if args.mode == "train" and not args.dynamic:
+        from pcdet_amd.models.inference import static_caps_for
+        core0 = model.module if hasattr(model, "module") else model
+        caps = static_caps_for(core0, batch, max(int(b["points"].shape[0]) for b in batches), training=True)
+    step = Step(model, optimizer, sched, cfg.OPTIMIZATION.GRAD_NORM_CLIP, args.mode, args.dense_dtype, static_caps=caps)
 
     for i in range(args.warmup):
         step(batches[i % len(batches)])
@@ -604,6 +621,8 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    from spx import ops as _ops
+    _ops.check_status(device)      # a static capacity that overflowed (rows dropped) would invalidate the number: raises
 
     line = None
     if rank == 0:
@@ -621,7 +640,9 @@ def main():
                                    (args.cfg - 1, geom["geom"]["name"].upper(), geom["n_points"], geom["n_active"],
                                     "fwd+bwd+AdamW step" if args.mode == "train" else "forward"),
                        "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": "dp%d" % world,
-                       "voxelize_on_gpu": True},
+                       "voxelize_on_gpu": True,
+                       "execution": "static row capacities, no host read in the step, rule tables on a second HIP stream"
+                                    if caps is not None else "exact-size sparse tensors"},
         }
     # ---- roofline: instrumented extra steps of the same workload (rank 0 prints; all ranks run them so DDP stays in step)
     if not args.no_roofline:

@@ -42,6 +42,8 @@ extern "C" {
 #define SPX_ERR_UNSUPPORTED (-3)  /* channel count / mode this build has no kernel for                     */
 #define SPX_ERR_LAUNCH (-4)       /* hipGetLastError() != hipSuccess after a launch                        */
 #define SPX_ERR_TOO_LARGE (-5)    /* rows >= 2^31 or grid cells >= 2^40                                    */
+#define SPX_ERR_CAPACITY (-7)     /* DEVICE-side: a strided rule table found more active outputs than the caller's row
+                                     capacity (static-capacity mode); rows beyond it were dropped; via d_status          */
 #define SPX_ERR_TABLE_FULL (-6)   /* DEVICE-side: a hash probe sequence found no free slot (stale workspace declared
                                      pre-cleared); reported through a d_status word, see spx_read_status()  */
 
@@ -155,7 +157,8 @@ int spx_subm_rulebook(const int32_t *idx, int64_t n, const int64_t *d_n, int bat
  *      cnt        device int32[K] (nullable);  d_n_out device int64[1] = number of active outputs
  *      cap        output-row capacity.  spx_conv_out_cap() = min(prod(ceil(k/s)) * n_in, batch*out cells) can never
  *                 overflow; a smaller static capacity is allowed (graph mode): rows beyond cap are dropped and
- *                 *d_n_out still reports the true count, so *d_n_out > cap signals overflow
+ *                 *d_n_out still reports the true count, so *d_n_out > cap signals overflow, and the status word
+ *                 d_status (nullable, see spx_read_status) receives SPX_ERR_CAPACITY
  * ---------------------------------------------------------------------------------------------- */
 int64_t spx_conv_out_cap(int64_t n_in, int batch, const int32_t *out_shape, const int32_t *ksize,
                          const int32_t *stride);
@@ -163,7 +166,7 @@ size_t spx_conv_rulebook_ws_bytes(int64_t n_in, int batch, const int32_t *out_sh
 int spx_conv_rulebook(const int32_t *idx, int64_t n_in, const int64_t *d_n_in, int batch, const int32_t *in_shape,
                       const int32_t *out_shape, const int32_t *ksize, const int32_t *stride, const int32_t *pad,
                       const int32_t *dil, int32_t *out_idx, int32_t *pair_fwd, int32_t *pair_bwd, int32_t *cnt,
-                      int64_t *d_n_out, int64_t cap, void *ws, size_t ws_bytes, spx_stream_t stream);
+                      int64_t *d_n_out, int64_t cap, int32_t *d_status, void *ws, size_t ws_bytes, spx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 4. Sparse convolution arithmetic
@@ -303,8 +306,9 @@ size_t spx_bn_relu_ws_bytes(int c);
 int spx_bn_relu_fwd(const float *x, int64_t n, const int64_t *d_n, int c, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, float momentum, float eps, int relu, float *y,
                     float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, spx_stream_t stream);
-/* backward: the ReLU mask is recomputed from x (same instruction sequence as the forward), y is not needed */
-int spx_bn_relu_bwd(const float *x, const float *dy, int64_t n, int c, const float *gamma, const float *beta,
+/* backward: the ReLU mask is recomputed from x (same instruction sequence as the forward), y is not needed; d_n (nullable)
+ * = device-side live row count as in the forward */
+int spx_bn_relu_bwd(const float *x, const float *dy, int64_t n, const int64_t *d_n, int c, const float *gamma, const float *beta,
                     const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma, float *dbeta,
                     void *ws, size_t ws_bytes, spx_stream_t stream);
 
@@ -319,8 +323,8 @@ int spx_bn_add_relu_fwd(const float *x, const float *res, int64_t n, const int64
                         const float *beta, float *running_mean, float *running_var, int64_t *num_batches_tracked,
                         float momentum, float eps, int relu, float *y, int64_t y_ld, float *save_mean, float *save_invstd,
                         void *ws, size_t ws_bytes, spx_stream_t stream);
-int spx_bn_add_relu_bwd(const float *x, const float *res, const float *dy, int64_t dy_ld, int64_t n, int c,
-                        const float *gamma, const float *beta, const float *save_mean, const float *save_invstd, int relu,
+int spx_bn_add_relu_bwd(const float *x, const float *res, const float *dy, int64_t dy_ld, int64_t n, const int64_t *d_n,
+                        int c, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd, int relu,
                         float *dx, float *dres, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
                         spx_stream_t stream);
 

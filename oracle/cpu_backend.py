@@ -100,7 +100,7 @@ def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=N
     return torch.from_numpy(out.astype(np.float32))
 
 
-def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
+def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None):
     x, g = _np(feat_in).astype(np.float32), _np(dout).astype(np.float32)
     p = _np(pair)[:, :n_out]
     cout, cin = wshape[0], wshape[-1]
@@ -117,7 +117,7 @@ def densify(features, indices, batch_size, spatial_shape, channels_last=False, d
     return torch.from_numpy(orc.densify(_np(features), _np(indices), batch_size, [int(s) for s in spatial_shape]))
 
 
-def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False):
+def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
     i = indices.long()
     return ddense[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]].contiguous()
 

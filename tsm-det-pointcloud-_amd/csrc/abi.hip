@@ -9,6 +9,7 @@ extern "C" const char* spx_strerror(int code) {
     case SPX_ERR_UNSUPPORTED: return "unsupported channel count or mode";
     case SPX_ERR_LAUNCH: return "HIP kernel launch failed";
     case SPX_ERR_TOO_LARGE: return "problem too large (rows >= 2^31 or grid cells >= 2^40)";
+    case SPX_ERR_CAPACITY: return "device: more active outputs than the static row capacity of a rule table; rows dropped";
     case SPX_ERR_TABLE_FULL: return "device: hash table full (workspace declared pre-cleared holds stale keys); rows dropped";
     default: return "unknown spx error code";
   }

@@ -186,12 +186,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ dy, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                      int64_t n, int C, int relu, const float* __restrict__ res,
-                                                      int64_t dy_ld, int cshift, float* __restrict__ dx,
-                                                      float* __restrict__ dres) {
-  const int64_t total4 = n * C / 4;
+                                                      int64_t n, const int64_t* d_n, int C, int relu,
+                                                      const float* __restrict__ res, int64_t dy_ld, int cshift,
+                                                      float* __restrict__ dx, float* __restrict__ dres) {
+  const int64_t nlive = spx_live_n(d_n, n);
+  const int64_t total4 = nlive * C / 4;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  const float invN = 1.0f / (float)n;
+  const float invN = 1.0f / (float)(nlive > 0 ? nlive : 1);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
     const int c0 = (int)((i * 4) % C);
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
@@ -253,8 +254,8 @@ extern "C" int spx_bn_add_relu_fwd(const float* x, const float* res, int64_t n, 
   return SPX_OK;
 }
 
-extern "C" int spx_bn_add_relu_bwd(const float* x, const float* res, const float* dy, int64_t dy_ld, int64_t n, int c,
-                                   const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+extern "C" int spx_bn_add_relu_bwd(const float* x, const float* res, const float* dy, int64_t dy_ld, int64_t n,
+                                   const int64_t* d_n, int c, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                                    int relu, float* dx, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                    spx_stream_t stream) {
   if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || n <= 0 || c <= 0)
@@ -268,10 +269,10 @@ extern "C" int spx_bn_add_relu_bwd(const float* x, const float* res, const float
   int nb = bn_blocks(n, c);
   const int cshift = log2_of(c);
   hipLaunchKernelGGL((k_bn_reduce<true>), dim3(nb), dim3(256), 0, s, x, gamma, beta, dy, save_mean, save_invstd, n,
-                     nullptr, c, relu, res, dy_ld, cshift, partial);
+                     d_n, c, relu, res, dy_ld, cshift, partial);
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(c), dim3(64), 0, s, partial, nb, c, dgamma, dbeta);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(nb), dim3(256), 0, s, x, beta, dy, save_mean, save_invstd, gamma, dgamma, dbeta,
-                     n, c, relu, res, dy_ld, cshift, dx, dres);
+                     n, d_n, c, relu, res, dy_ld, cshift, dx, dres);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }
@@ -283,9 +284,10 @@ extern "C" int spx_bn_relu_fwd(const float* x, int64_t n, const int64_t* d_n, in
                              c, save_mean, save_invstd, ws, ws_bytes, stream);
 }
 
-extern "C" int spx_bn_relu_bwd(const float* x, const float* dy, int64_t n, int c, const float* gamma, const float* beta,
+extern "C" int spx_bn_relu_bwd(const float* x, const float* dy, int64_t n, const int64_t* d_n, int c, const float* gamma,
+                               const float* beta,
                                const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
                                float* dbeta, void* ws, size_t ws_bytes, spx_stream_t stream) {
-  return spx_bn_add_relu_bwd(x, nullptr, dy, c, n, c, gamma, beta, save_mean, save_invstd, relu, dx, nullptr, dgamma, dbeta, ws,
+  return spx_bn_add_relu_bwd(x, nullptr, dy, c, n, d_n, c, gamma, beta, save_mean, save_invstd, relu, dx, nullptr, dgamma, dbeta, ws,
                              ws_bytes, stream);
 }

@@ -174,7 +174,7 @@ __global__ void k_scan_blocksum(const uint64_t* __restrict__ bits, int64_t nword
 }
 
 // single block: exclusive scan of blocksum in place, total -> d_n_out
-__global__ void k_scan_top(uint32_t* blocksum, int64_t nblk, int64_t* d_n_out) {
+__global__ void k_scan_top(uint32_t* blocksum, int64_t nblk, int64_t* d_n_out, int64_t cap, int32_t* status) {
   __shared__ uint32_t carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
@@ -189,7 +189,11 @@ __global__ void k_scan_top(uint32_t* blocksum, int64_t nblk, int64_t* d_n_out) {
     if (threadIdx.x == 0) carry_s = carry + total;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *d_n_out = (int64_t)carry_s;
+  if (threadIdx.x == 0) {
+    *d_n_out = (int64_t)carry_s;
+    // more active cells than the caller's row capacity: rows beyond it are dropped — never silently
+    if (status && (int64_t)carry_s > cap) atomicMin(status, (int32_t)SPX_ERR_CAPACITY);
+  }
 }
 
 __global__ void k_scan_expand(const uint64_t* __restrict__ bits, int64_t nwords, const uint32_t* __restrict__ blocksum,
@@ -378,7 +382,7 @@ extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t
                                  const int32_t* in_shape, const int32_t* out_shape, const int32_t* ksize,
                                  const int32_t* stride, const int32_t* pad, const int32_t* dil, int32_t* out_idx,
                                  int32_t* pair_fwd, int32_t* pair_bwd, int32_t* cnt, int64_t* d_n_out, int64_t cap,
-                                 void* ws, size_t ws_bytes, spx_stream_t stream) {
+                                 int32_t* d_status, void* ws, size_t ws_bytes, spx_stream_t stream) {
   if ((!idx && n_in > 0) || !in_shape || !out_shape || !ksize || !stride || !pad || !dil || !out_idx || !pair_fwd || !pair_bwd ||
       !d_n_out || n_in < 0 || batch <= 0 || cap <= 0)
     return SPX_ERR_INVALID_ARG;
@@ -408,7 +412,7 @@ extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t
   unsigned nb_in = (unsigned)((n_in + kBlock - 1) / kBlock);
   if (n_in > 0) hipLaunchKernelGGL(k_mark, dim3(nb_in, K), dim3(kBlock), 0, s, idx, n_in, d_n_in, batch, g, w.bits);
   hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, w.blocksum, w.nblk, d_n_out);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, w.blocksum, w.nblk, d_n_out, cap, d_status);
   hipLaunchKernelGGL(k_scan_expand, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum, w.prefix,
                      g.out_shape, out_idx, cap);
   unsigned nb_cap = (unsigned)((cap + kBlock - 1) / kBlock);
@@ -610,7 +614,7 @@ extern "C" int spx_dynamic_voxelize(const float* points, int64_t n_points, int s
     hipLaunchKernelGGL(k_dyn_mark, dim3(nbp), dim3(kBlock), 0, s, points, n_points, stride, batch_col, xyz_col, batch, g,
                        w.bits, w.keys);
   hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, w.blocksum, w.nblk, d_num_voxels);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, w.blocksum, w.nblk, d_num_voxels, cap, (int32_t*)nullptr);
   Int3 shape;
   shape.v[0] = grid3[0], shape.v[1] = grid3[1], shape.v[2] = grid3[2];
   hipLaunchKernelGGL(k_scan_expand, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum, w.prefix, shape,

@@ -43,9 +43,13 @@ __device__ __forceinline__ int64_t spx_lin_key(int b, int z, int y, int x, const
 
 __device__ __forceinline__ int spx_lane() { return threadIdx.x & 63; }
 
-// Device-side fill used instead of hipMemsetAsync: byte-pattern memset NODES of a captured hipGraph did not re-initialise
-// the workspace on the second replay (ROCm 7.x, observed as an endless CAS probe in the voxeliser's hash), whereas kernel
-// nodes replay correctly.  `bytes` must be a multiple of 4 (every buffer of this library is).
+// Device-side fill instead of hipMemsetAsync.  Round 1 saw an endless CAS probe in the voxeliser on the second replay of
+// a torch-captured hipGraph while this helper was a byte-pattern hipMemsetAsync, and switched to a fill kernel.  Round 2
+// looked for the cause (profiles/r02_graph_memset_probe.log, tools/hip/graph_memset_probe.hip, tools/graph_memset_in_lib.py):
+// stand-alone, memset NODES replay correctly on this ROCm for every size / pattern the library uses, so the stall is not
+// pinned on them; what made it a HANG rather than a wrong answer were the unbounded probe loops, which are now bounded
+// (SPX_ERR_TABLE_FULL).  The fill kernel stays: one code path for eager and captured execution, and -DSPX_FILL_USE_MEMSET
+// (dev builds only) restores the memset form for that A/B.  `bytes` must be a multiple of 4 (every buffer here is).
 static __global__ void spx_k_fill32(uint32_t* __restrict__ p, uint32_t v, size_t nwords) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -54,6 +58,10 @@ static __global__ void spx_k_fill32(uint32_t* __restrict__ p, uint32_t v, size_t
 
 static inline void spx_fill_async(void* ptr, int byte_value, size_t bytes, hipStream_t s) {
   if (bytes == 0) return;
+#ifdef SPX_FILL_USE_MEMSET
+  (void)hipMemsetAsync(ptr, byte_value, bytes, s);
+  return;
+#endif
   const uint32_t b = (uint32_t)(byte_value & 0xFF);
   const uint32_t v = b | (b << 8) | (b << 16) | (b << 24);
   const size_t nwords = bytes / 4;

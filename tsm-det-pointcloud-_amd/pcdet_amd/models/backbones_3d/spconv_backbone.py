@@ -13,6 +13,7 @@ import torch.nn as nn
 
 import spx as spconv
 from spx.functional import bn_act
+from spx.prebuild import prebuild
 
 from ...utils.spconv_utils import replace_feature  # noqa: F401  (API parity)
 
@@ -55,10 +56,10 @@ class SparseBasicBlock(spconv.SparseModule):
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
         out = self.conv1(x)
-        out = out.replace_feature(bn_act(out.features, self.bn1, True))
+        out = out.replace_feature(bn_act(out.features, self.bn1, True, d_n=out.n_valid))
         out = self.conv2(out)
         # bn2 + identity + ReLU: one fused kernel pair in training (spx_bn_add_relu_*), the torch modules otherwise
-        out = out.replace_feature(bn_act(out.features, self.bn2, True, identity.features))
+        out = out.replace_feature(bn_act(out.features, self.bn2, True, identity.features, d_n=out.n_valid))
         return out
 
 
@@ -97,11 +98,19 @@ class _TablesAhead(object):
         self.launch(next_stage, rb.out_indices, rb.out_shape)
 
 
+def _queue_tables(self, x):
+    """Static-capacity tensors: every rule table of the stack (+ grouping and work plans) goes to the index stream now and
+    is built in the shadow of the convolutions (spx/prebuild.py); exact-size tensors build theirs lazily, as before."""
+    if x.n_valid is not None:
+        prebuild(x, [m for m in self.modules() if isinstance(m, spconv.SparseConvolution)])
+
+
 def _run_8x_stack(self, batch_dict, with_points_keys):
     voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
     x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords.int(), spatial_shape=self.sparse_shape,
                                 batch_size=batch_dict['batch_size'], n_valid=batch_dict.get('voxel_num_valid', None),
                                 static_caps=batch_dict.get('static_caps', None))
+    _queue_tables(self, x)
     # A strided rule table has to tell the host its row count.  Each one is LAUNCHED one stage early — its kernels sit in
     # the stream in front of the previous stage's convolutions — and its count is picked up after that stage has been
     # queued, so the host never waits on an empty GPU (same tables, found by the modules under their indice_key).
@@ -214,6 +223,7 @@ class VoxelBackBone8x(nn.Module):
                                     spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'],
                                     n_valid=batch_dict.get('voxel_num_valid', None),
                                     static_caps=batch_dict.get('static_caps', None))
+        _queue_tables(self, x)
         x = self.conv_input(x)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)

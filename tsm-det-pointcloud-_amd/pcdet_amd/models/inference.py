@@ -17,6 +17,22 @@ import torch
 DEFAULT_LEVEL_FACTORS = {'spconv2': 2.0, 'spconv3': 2.0, 'spconv4': 1.0, 'spconv_down2': 1.0}
 
 
+def static_caps_for(model, batch_size, n_points, training=None, level_factors=None):
+    """Row capacities for the host-sync-free (static-capacity) execution of `model` on batches of at most `n_points`
+    points: put the returned dict in batch_dict['static_caps'] (training or eval).  The voxel capacity is exact — the
+    reference's hard cap min(points, batch * MAX_NUMBER_OF_VOXELS[mode]); the output rows of each strided conv get
+    `level_factors` x that (the no-overflow bound is 8x per stage and would size every later kernel for rows that never
+    exist).  An overflow never passes silently: the rule-table kernels raise SPX_ERR_CAPACITY in the device status word
+    (spx.ops.check_status) and the live counts stay readable in the tensors' n_valid."""
+    training = model.training if training is None else training
+    vox_cap = min(int(n_points), int(batch_size) * int(model.vfe.max_voxels['train' if training else 'test']))
+    f = dict(DEFAULT_LEVEL_FACTORS)
+    f.update(level_factors or {})
+    caps = {k: max(1, int(v * vox_cap)) for k, v in f.items()}
+    caps['voxels'] = vox_cap
+    return caps
+
+
 class GraphedDetector(object):
     def __init__(self, model, batch_size, max_points, level_factors=None, warmup=2, n_modules=None):
         """n_modules: run only the first n modules of model.module_list (3 = voxelise + VFE, 3-D backbone, BEV collapse)."""

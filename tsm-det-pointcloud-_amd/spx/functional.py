@@ -77,7 +77,7 @@ class _SparseConvFn(torch.autograd.Function):
         sh = shift if shift is not None else bias
         out = _conv(feats, wp, cout, kvol, pair_f, ld_f, n_dst, False, scale, sh, relu, d_n, rb)
         ctx.save_for_backward(feats, weight)
-        ctx.rb, ctx.d_n_src = rb, d_n_src
+        ctx.rb, ctx.d_n_src, ctx.d_n = rb, d_n_src, d_n
         ctx.tables = (pair_f, ld_f, n_dst, pair_b, ld_b, flip_b)
         ctx.has_bias = bias is not None
         ctx.fused = scale is not None or shift is not None or relu
@@ -89,12 +89,13 @@ class _SparseConvFn(torch.autograd.Function):
             raise RuntimeError("fused scale/shift/relu epilogue is inference-only")
         feats, weight = ctx.saved_tensors
         dfe, dw, db = _conv_backward(feats, weight, ctx.tables, ctx.rb, ctx.d_n_src, ctx.has_bias, dout,
-                                     ctx.needs_input_grad[:3])
+                                     ctx.needs_input_grad[:3], ctx.d_n)
         return dfe, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def _conv_backward(feats, weight, tables, rb, d_n_src, has_bias, dout, needs):
-    """dgrad (the same gather-GEMM with transposed weights over the backward table), wgrad, bias gradient."""
+def _conv_backward(feats, weight, tables, rb, d_n_src, has_bias, dout, needs, d_n_dst=None):
+    """dgrad (the same gather-GEMM with transposed weights over the backward table), wgrad, bias gradient.  d_n_src /
+    d_n_dst: device-side live row counts of the layer's input / output in static-capacity mode."""
     pair_f, ld_f, n_dst, pair_b, ld_b, flip_b = tables
     cout, cin = weight.shape[0], weight.shape[-1]
     kvol = weight.numel() // (cout * cin)
@@ -104,8 +105,11 @@ def _conv_backward(feats, weight, tables, rb, d_n_src, has_bias, dout, needs):
         wt = _packed(weight, 1)
         dfe = _conv(dout, wt, cin, kvol, pair_b, ld_b, feats.shape[0], flip_b, None, None, False, d_n_src, rb)
     if needs[1]:
-        dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape))
+        dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape), d_n_out=d_n_dst)
     if has_bias and needs[2]:
+        if d_n_dst is not None:
+            raise RuntimeError("bias gradient of a static-capacity tensor is not implemented (rows beyond the live count "
+                               "are undefined)")
         db = dout.sum(0)
     return dfe, dw, db
 
@@ -124,18 +128,19 @@ class _SparseConvBNReLUFn(torch.autograd.Function):
         kvol = weight.numel() // (cout * cin)
         out = _conv(feats, _packed(weight, 0), cout, kvol, pair_f, ld_f, n_dst, False, None, bias, False, d_n, rb)
         y, mean, invstd = ops.bn_relu_fwd(out, gamma, beta, running_mean, running_var, momentum, eps, relu,
-                                          num_batches_tracked=nbt)
+                                          num_batches_tracked=nbt, d_n=d_n)
         ctx.save_for_backward(feats, weight, out, gamma, beta, mean, invstd)
         ctx.tables, ctx.rb, ctx.d_n_src, ctx.has_bias, ctx.relu = tables, rb, d_n_src, bias is not None, relu
+        ctx.d_n = d_n
         ctx.mark_non_differentiable(running_mean, running_var)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         feats, weight, out, gamma, beta, mean, invstd = ctx.saved_tensors
-        dout, dgamma, dbeta = ops.bn_relu_bwd(out, dy, gamma, beta, mean, invstd, ctx.relu)
+        dout, dgamma, dbeta = ops.bn_relu_bwd(out, dy, gamma, beta, mean, invstd, ctx.relu, d_n=ctx.d_n)
         dfe, dw, db = _conv_backward(feats, weight, ctx.tables, ctx.rb, ctx.d_n_src, ctx.has_bias, dout,
-                                     ctx.needs_input_grad[:3])
+                                     ctx.needs_input_grad[:3], ctx.d_n)
         return dfe, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
@@ -165,13 +170,14 @@ def sparse_conv(feats, weight, bias, rb, inverse=False, scale=None, shift=None, 
 class _DenseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, indices, batch_size, spatial_shape, channels_last, d_n=None):
-        ctx.args = (indices, batch_size, list(spatial_shape), channels_last)
+        ctx.args = (indices, batch_size, list(spatial_shape), channels_last, d_n)
         return ops.densify(feats, indices, batch_size, spatial_shape, channels_last, d_n=d_n)
 
     @staticmethod
     def backward(ctx, ddense):
-        indices, batch_size, spatial_shape, channels_last = ctx.args
-        return ops.densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last), None, None, None, None, None
+        indices, batch_size, spatial_shape, channels_last, d_n = ctx.args
+        return (ops.densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last, d_n=d_n), None, None, None, None,
+                None)
 
 
 def dense(feats, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
@@ -182,9 +188,10 @@ class _BNReLUFn(torch.autograd.Function):
     """Training-mode BatchNorm1d (+ residual) (+ReLU) on sparse feature rows: libspx kernels forward and backward."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None, nbt=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None, nbt=None, d_n=None):
         y, mean, invstd = ops.bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual,
-                                          num_batches_tracked=nbt)
+                                          num_batches_tracked=nbt, d_n=d_n)
+        ctx.d_n = d_n
         if residual is None:
             ctx.save_for_backward(x, gamma, beta, mean, invstd)
         else:
@@ -197,8 +204,9 @@ class _BNReLUFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma, beta, mean, invstd = ctx.saved_tensors[:5]
         residual = ctx.saved_tensors[5] if len(ctx.saved_tensors) > 5 else None
-        out = ops.bn_relu_bwd(x, dy, gamma, beta, mean, invstd, ctx.relu, residual)
-        return out[0], out[1], out[2], None, None, None, None, None, (out[3] if residual is not None else None), None
+        out = ops.bn_relu_bwd(x, dy, gamma, beta, mean, invstd, ctx.relu, residual, d_n=ctx.d_n)
+        return (out[0], out[1], out[2], None, None, None, None, None, (out[3] if residual is not None else None), None,
+                None)
 
 
 class _BNReLUCatFn(torch.autograd.Function):
@@ -264,19 +272,22 @@ def bn_train_fusable(bn, f):
             and f.dtype == torch.float32 and f.dim() == 2 and f.shape[0] > 1 and ops.bn_relu_supported(f.shape[1]))
 
 
-def bn_relu_train(x, bn, relu, residual=None):
+def bn_relu_train(x, bn, relu, residual=None, d_n=None):
     """x [N, C] through `bn` (nn.BatchNorm1d in training mode, affine, tracking running stats), plus `residual` when
-    given, and optionally ReLU."""
+    given, and optionally ReLU.  d_n: device-side live row count of a static-capacity tensor."""
     # num_batches_tracked is incremented inside the finalize kernel (one launch less per layer)
     return _BNReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, residual,
-                           bn.num_batches_tracked)
+                           bn.num_batches_tracked, d_n)
 
 
-def bn_act(x, bn, relu, residual=None):
+def bn_act(x, bn, relu, residual=None, d_n=None):
     """relu(bn(x) + residual) on feature rows: the fused kernels when they apply (training on the GPU), else the torch
-    modules in the reference's order (spconv_backbone.py:56-72)."""
+    modules in the reference's order (spconv_backbone.py:56-72).  d_n: live row count of a static-capacity tensor (only
+    the fused kernels can honour it)."""
     if bn_train_fusable(bn, x):
-        return bn_relu_train(x, bn, relu, residual)
+        return bn_relu_train(x, bn, relu, residual, d_n)
+    if d_n is not None:
+        raise RuntimeError("static-capacity rows need the fused BatchNorm kernels (training mode on the GPU, fp32)")
     y = bn(x)
     if residual is not None:
         y = y + residual

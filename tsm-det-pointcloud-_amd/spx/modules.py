@@ -16,6 +16,7 @@ from torch import nn
 
 from . import functional as F_
 from . import ops
+from . import prebuild as _prebuild
 from .tensor import SparseConvTensor
 
 
@@ -92,7 +93,7 @@ class SparseSequential(SparseModule):
                 if tail is not None:
                     # training: BatchNorm1d (batch statistics) + ReLU as one libspx kernel pair instead of 3 + 3 launches
                     bn, relu, consumed = tail
-                    input = input.replace_feature(F_.bn_relu_train(input.features, bn, relu))
+                    input = input.replace_feature(F_.bn_relu_train(input.features, bn, relu, d_n=input.n_valid))
                     i += consumed
                     continue
             elif isinstance(input, SparseConvTensor):
@@ -114,8 +115,7 @@ def _train_bn_pre(conv, mods, i, x):
     """(bn, relu, modules consumed) when mods[i:] is a non-inverse SparseConvolution followed by a training-mode
     BatchNorm1d[, ReLU] that libspx covers — decided before the conv runs, from its out_channels — so that the three run
     as one autograd node (F_.sparse_conv_bn_relu)."""
-    if (not _FUSED_BLOCK or not is_sparse_conv(conv) or conv.inverse or i + 1 >= len(mods) or x.n_valid is not None
-            or not x.features.is_cuda):
+    if not _FUSED_BLOCK or not is_sparse_conv(conv) or conv.inverse or i + 1 >= len(mods) or not x.features.is_cuda:
         return None
     bn = mods[i + 1]
     if not (isinstance(bn, nn.BatchNorm1d) and bn.training and bn.affine and bn.track_running_stats
@@ -129,7 +129,7 @@ def _train_bn_pre(conv, mods, i, x):
 def _train_bn_tail(mods, i, x):
     """(bn, relu, modules consumed) when mods[i+1:] starts with a training-mode affine BatchNorm1d[, ReLU] that libspx's
     fused kernels cover; else None (the torch modules then run as usual)."""
-    if i + 1 >= len(mods) or x.n_valid is not None:
+    if i + 1 >= len(mods):
         return None
     bn = mods[i + 1]
     f = x.features
@@ -216,6 +216,8 @@ class SparseConvolution(SparseModule):
     def _rulebook(self, x):
         """Find (indice_key cache) or build the rulebook; returns (rulebook, out_indices, out_shape)."""
         cached = x.find_indice_pair(self.indice_key)
+        if cached is not None:
+            _prebuild.wait_ready(cached)        # a table queued on the index stream (spx/prebuild.py)
         if self.inverse:
             if cached is None:
                 raise ValueError("SparseInverseConv3d needs the rulebook of the conv with indice_key=%r"
@@ -251,7 +253,7 @@ class SparseConvolution(SparseModule):
             out_feats = F_.sparse_conv_bn_relu(feats, self.weight, self.bias, rb, train_bn[0], train_bn[1])
         elif train_bn is not None:
             out_feats = F_.sparse_conv(feats, self.weight, self.bias, rb, inverse=self.inverse)
-            out_feats = F_.bn_act(out_feats, train_bn[0], train_bn[1])
+            out_feats = F_.bn_act(out_feats, train_bn[0], train_bn[1], d_n=(rb.d_n_in if self.inverse else rb.d_n_out))
         elif fused is not None:
             scale, shift, relu = fused      # shift already contains the conv bias
             out_feats = F_.sparse_conv(feats, self.weight, None, rb, inverse=self.inverse, scale=scale, shift=shift,

@@ -243,9 +243,11 @@ def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, di
     d_n = torch.zeros((1,), dtype=torch.int64, device=dev)
     wsb = lib.spx_conv_rulebook_ws_bytes(n_in, batch_size, i3(out_shape))
     ws = workspace(dev, wsb)
+    # a capacity below the no-overflow bound can drop rows: the kernels say so in the sticky status word (check_status)
+    d_st = _ptr(status_word(dev)) if cap < safe_cap else None
     check(lib.spx_conv_rulebook(_ptr(indices), n_in, _ptr(d_n_in), batch_size, i3(spatial_shape), i3(out_shape), i3(ksize),
                                 i3(stride), i3(padding), i3(dilation), _ptr(out_idx), _ptr(pair_fwd), _ptr(pair_bwd),
-                                _ptr(cnt), _ptr(d_n), cap, _ptr(ws), wsb, _stream(indices)), "spx_conv_rulebook")
+                                _ptr(cnt), _ptr(d_n), cap, d_st, _ptr(ws), wsb, _stream(indices)), "spx_conv_rulebook")
     if not sync:
         rb = Rulebook(pair_fwd, cap, n_in, cap, K, False, out_idx, out_shape, spatial_shape, pair_bwd=pair_bwd, cnt=cnt,
                       ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation))
@@ -405,7 +407,8 @@ def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k
     return dst
 
 
-def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
+def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None):
+    """d_n_out: optional device int64[1] live output-row count (n_out is then the capacity)."""
     _need_gpu(feat_in, dout, pair)
     lib = _lib.load()
     feat_in = feat_in.contiguous()
@@ -419,7 +422,7 @@ def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
         return dw.zero_()
     wsb = lib.spx_conv_wgrad_ws_bytes(cin, cout, K, n_out)
     ws = workspace(dout.device, wsb)
-    check(lib.spx_conv_wgrad(_ptr(feat_in), cin, _ptr(dout), cout, K, _ptr(pair), ld, n_out, None, _ptr(dw), _ptr(ws),
+    check(lib.spx_conv_wgrad(_ptr(feat_in), cin, _ptr(dout), cout, K, _ptr(pair), ld, n_out, _ptr(d_n_out), _ptr(dw), _ptr(ws),
                              wsb, _stream(dout)), "spx_conv_wgrad")
     return dw
 
@@ -444,7 +447,7 @@ def densify(features, indices, batch_size, spatial_shape, channels_last=False, d
     return dense.permute(0, 3, 4, 1, 2) if channels_last else dense
 
 
-def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False):
+def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
     _need_gpu(ddense, indices)
     lib = _lib.load()
     n = indices.shape[0]
@@ -454,7 +457,7 @@ def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False)
     else:
         dd = ddense.contiguous()
     dfeat = torch.empty((n, c), dtype=torch.float32, device=ddense.device)
-    check(lib.spx_densify_bwd(_ptr(dd), _ptr(indices), n, None, c, batch_size, i3(spatial_shape),
+    check(lib.spx_densify_bwd(_ptr(dd), _ptr(indices), n, _ptr(d_n), c, batch_size, i3(spatial_shape),
                               1 if channels_last else 0, _ptr(dfeat), _stream(ddense)), "spx_densify_bwd")
     return dfeat
 
@@ -553,7 +556,7 @@ def _row_view_ok(t, n, c):
 
 
 def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None, out=None,
-                num_batches_tracked=None):
+                num_batches_tracked=None, d_n=None):
     """Training-mode BatchNorm1d over the rows of x [N, C] (+ residual) (+ReLU).  Updates running_mean / running_var
     (and num_batches_tracked, when given) in place.  `out`: optional [N, C] view with its own row stride (a channel
     slice of a wider matrix) that receives y.  Returns y, save_mean, save_invstd."""
@@ -576,14 +579,14 @@ def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, 
     invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
     wsb = lib.spx_bn_relu_ws_bytes(c)
     ws = workspace(x.device, wsb)
-    check(lib.spx_bn_add_relu_fwd(_ptr(x), _ptr(residual), n, None, c, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+    check(lib.spx_bn_add_relu_fwd(_ptr(x), _ptr(residual), n, _ptr(d_n), c, _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                   _ptr(running_var), _ptr(num_batches_tracked), float(momentum), float(eps),
                                   int(bool(relu)), _ptr(y), y_ld, _ptr(mean), _ptr(invstd), _ptr(ws), wsb, _stream(x)),
           "spx_bn_add_relu_fwd")
     return y, mean, invstd
 
 
-def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu, residual=None):
+def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu, residual=None, d_n=None):
     """Backward of bn_relu_fwd; the ReLU mask is recomputed from x (and the residual) inside the kernels (y is not
     read).  dy may be a row view with its own stride (a channel slice of a wider gradient).  Returns dx, dgamma, dbeta
     and, with a residual, dresidual."""
@@ -602,7 +605,7 @@ def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu, residual=None):
         return out if residual is None else out + (dres,)
     wsb = lib.spx_bn_relu_ws_bytes(c)
     ws = workspace(x.device, wsb)
-    check(lib.spx_bn_add_relu_bwd(_ptr(x), _ptr(residual), _ptr(dy), dy_ld, n, c, _ptr(gamma), _ptr(beta), _ptr(mean),
+    check(lib.spx_bn_add_relu_bwd(_ptr(x), _ptr(residual), _ptr(dy), dy_ld, n, _ptr(d_n), c, _ptr(gamma), _ptr(beta), _ptr(mean),
                                   _ptr(invstd), int(bool(relu)), _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
                                   wsb, _stream(x)), "spx_bn_add_relu_bwd")
     return (dx, dgamma, dbeta) if residual is None else (dx, dgamma, dbeta, dres)
