@@ -205,7 +205,7 @@ class KernelTimer(object):
             # reads the table, writes perm and the grouped table
             return t._timed("conv_group", 0.0, 4.0 * (2 * kvol + 1) * n_dst, sv["conv_group"], pair, ld, kvol, n_dst, d_n_dst)
 
-        def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape):
+        def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None):
             cout, cin = wshape[0], wshape[-1]
             K = int(np.prod(wshape[1:-1]))
             P = t._P(pair, n_out)
@@ -213,7 +213,7 @@ class KernelTimer(object):
             nbytes = 4.0 * (feat_in.shape[0] * cin + n_out * cout + K * n_out + K * cin * cout)
             # one family per template instantiation (k_wgrad_mfma<cin/16, cout/16, ..>), like the forward kernels
             return t._timed("conv_wgrad[mfma %dx%d]" % (cin, cout), flops, nbytes, sv["conv_wgrad"], feat_in, dout, pair, ld,
-                            n_out, wshape)
+                            n_out, wshape, d_n_out)
 
         def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None):
             n = indices.shape[0]
@@ -237,7 +237,8 @@ class KernelTimer(object):
             out = sv["voxelize"](points, *a, **k)
             e1.record()
             c = out["mean"].shape[1] if out["mean"] is not None else 4
-            t.rec.append(("voxelize+meanvfe", 0.0, 4.0 * points.shape[0] * c + 4.0 * out["num_voxels"] * (c + 4), e0, e1))
+            nv = out["num_voxels"] if out["num_voxels"] is not None else int(out["d_num_voxels"].item())
+            t.rec.append(("voxelize+meanvfe", 0.0, 4.0 * points.shape[0] * c + 4.0 * nv * (c + 4), e0, e1))
             return out
 
         def densify(features, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
@@ -246,10 +247,10 @@ class KernelTimer(object):
             return t._timed("densify(+memset)", 0.0, 4.0 * (n * c + c * cells), sv["densify"], features, indices,
                             batch_size, spatial_shape, channels_last, d_n)
 
-        def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False):
+        def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
             n, c = indices.shape[0], ddense.shape[1]
             return t._timed("densify_bwd", 0.0, 8.0 * n * c, sv["densify_bwd"], ddense, indices, batch_size,
-                            spatial_shape, channels_last)
+                            spatial_shape, channels_last, d_n)
 
         def pack_weight(weight, mode):
             return t._timed("pack_weight", 0.0, 8.0 * weight.numel(), sv["pack_weight"], weight, mode)
@@ -648,6 +649,9 @@ def main():
     if not args.no_roofline:
         kt = KernelTimer()
         kt.install()
+        # algorithmic FLOPs / bytes need exact row counts on the host: the instrumented steps run the exact-size path (the
+        # same kernels; at static capacity their grids only carry extra blocks that exit at once)
+        step.static_caps = None
         n_inst = 3
         for i in range(n_inst):
             step(batches[i % len(batches)])

@@ -1,7 +1,7 @@
 """Dev probe (GPU box): the round-1 graph-replay stall, looked for INSIDE the library.  Builds a variant of libspx whose
 workspace clears are hipMemsetAsync calls again (-DSPX_FILL_USE_MEMSET) into gpurun_out/, captures the sync-free backbone
 forward (voxelise -> 8 rule tables -> 12 convs -> densify) into a hipGraph with each build and replays it 4 times on two
-different batches, checking after every replay the voxel count, the BEV map against the eager result and the device status
+different batches, checking after every replay the voxel count, the BEV map against the eager result (relative difference: the capacity path may pick another kernel schedule) and the device status
 word (SPX_ERR_TABLE_FULL = a probe sequence met a table that was not cleared).  Probe loops are bounded since round 2, so a
 stale workspace shows up as an error code / a mismatch here, not as a hang.
 
@@ -62,10 +62,11 @@ for rep in range(4):
     out = g(p)
     torch.cuda.synchronize()
     nv = int(out["counts"]["voxels"])
-    same = torch.equal(out["spatial_features"], refs[rep %% 2][1])
+    ref = refs[rep %% 2][1]
+    same = "%%.1e" %% float((out["spatial_features"] - ref).abs().max() / ref.abs().max())
     st = int(ops.status_word(dev).item())
     ops.status_word(dev).zero_()
-    print("%s replay %%d: voxels %%d (eager %%d)  BEV map == eager: %%s  device status %%d" %% (rep + 1, nv, refs[rep %% 2][0], same, st))
+    print("%s replay %%d: voxels %%d (eager %%d)  BEV map max rel diff vs eager: %%s  device status %%d" %% (rep + 1, nv, refs[rep %% 2][0], same, st))
 ''' % (ROOT, os.path.join(ROOT, "tsm-det-pointcloud-_amd"), bool(lib_path), lib_path, ROOT, tag)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     sys.stdout.write(r.stdout)
