@@ -197,7 +197,10 @@ int spx_conv_gemm(const float *src, int c_src, const float *w_packed, int c_dst,
  * (16-row tile, offset) units of a rule table once and cuts them into equal ranges for a persistent grid; the plan
  * depends only on (pair, n_dst), so it is reused by every convolution that reads the table (forward, dgrad with
  * flip_k, the second layer of a submanifold pair).  spx_conv_gemm_balanced = spx_conv_gemm under that schedule;
- * returns SPX_ERR_UNSUPPORTED for channel pairs it does not cover (use spx_conv_gemm).  Same reference call sites. */
+ * returns SPX_ERR_UNSUPPORTED for channel pairs it does not cover (use spx_conv_gemm).  Same reference call sites.
+ * Super-tiles whose offsets are split between workgroups are combined inside the launch (arrival counters kept in `plan`,
+ * which is therefore not const: one launch per plan at a time — stream order is enough); partial sums are added in a fixed
+ * order, so results are bitwise reproducible. */
 /* Optional row order for that schedule (csrc/conv_group.hip): a 16-row MFMA tile multiplies offset k for all its rows
  * as soon as one of them has it, so tiles whose rows share the same offsets issue fewer wasted MFMAs.  spx_conv_group
  * sorts the destination rows of a rule table by their offset mask (stable) and writes perm[n_dst] (position -> table row)
@@ -214,7 +217,7 @@ int spx_conv_plan(const int32_t *pair, int64_t pair_ld, int kvol, int64_t n_dst,
 size_t spx_conv_gemm_balanced_ws_bytes(int c_dst, int64_t n_dst);
 int spx_conv_gemm_balanced(const float *src, int c_src, const float *w_packed, int c_dst, int kvol, int flip_k,
                            const int32_t *pair, int64_t pair_ld, int64_t n_dst, const int64_t *d_n_dst,
-                           const float *scale, const float *shift, int relu, const int32_t *plan, const int32_t *perm,
+                           const float *scale, const float *shift, int relu, int32_t *plan, const int32_t *perm,
                            float *dst, void *ws, size_t ws_bytes, spx_stream_t stream);
 
 size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n_out);

@@ -338,7 +338,8 @@ def test_conv_balanced_schedule_matches_tile_per_wave(orc):
 
 @pytest.mark.parametrize("frames,n_live", [(4, None), (1, None), (2, 9000)])
 def test_conv_grouped_row_order(frames, n_live, orc):
-    """spx_conv_group: perm is the stable sort of the rows by offset mask (a permutation; dead rows last), the grouped
+    """spx_conv_group: perm is the stable sort of the rows by (window, offset mask) — eight windows of the live rows, one per
+    XCD — (a permutation; dead rows last), the grouped
     table is the table read through perm, the plan over it holds fewer (super-tile, offset) units, and the balanced
     conv over the grouped rows returns the rows of the ungrouped result (same per-row sums) — forward, flipped, with
     the fused epilogue, and with a device-side live-row count."""
@@ -354,7 +355,9 @@ def test_conv_grouped_row_order(frames, n_live, orc):
     perm, grouped = ops.conv_group(sub.pair, sub.ld, K, n, d_n)
     pair = sub.pair[:, :n]
     mask = ((pair >= 0).to(torch.int64) << torch.arange(K, device=dev)[:, None]).sum(0)
-    key = torch.where(torch.arange(n, device=dev) < live, mask, torch.full_like(mask, 1 << 30))
+    rows = torch.arange(n, device=dev)
+    wsz = (live + 7) // 8
+    key = torch.where(rows < live, ((rows // wsz) << 27) | mask, torch.full_like(mask, 1 << 31))
     assert torch.equal(perm.long(), torch.argsort(key, stable=True))
     want = pair[:, perm.long()].clone()
     want[:, live:] = -1
@@ -827,3 +830,37 @@ def test_dirty_precleared_workspace_reports_table_full_instead_of_hanging(orc):
 def ctypes_ptr(t):
     import ctypes
     return ctypes.c_void_p(t.data_ptr())
+
+
+def test_conv_balanced_empty_tiles_and_combine(orc):
+    """Rule tables with whole 64-row super-tiles that have no pair at all (they must come out as epilogue(0), written by
+    the main kernel now that the fix-up pass is gone), a table with no pair anywhere, and the in-launch combine of
+    super-tiles split between workgroups: against spx_conv_gemm on the same tables, bitwise stable over repeated launches
+    of the same plan (the arrival counters are reset by each last arriver)."""
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, 2, 2)
+    dev = _dev()
+    d_idx = torch.from_numpy(idx_np).to(dev)
+    g = torch.Generator().manual_seed(23)
+    sub = ops.subm_rulebook(d_idx, 2, shape, (3, 3, 3))
+    n = sub.n_out
+    holes = sub.pair.clone()
+    holes[:, 128:320] = -1                       # three empty super-tiles in the middle
+    holes[:, n - 100:] = -1                      # and a ragged empty tail
+    none = torch.full_like(sub.pair, -1)
+    for (cs, cd) in ((64, 64), (128, 128)):
+        w = (torch.randn(cd, 3, 3, 3, cs, generator=g) / np.sqrt(27 * cs)).to(dev)
+        wp = ops.pack_weight(w, 0)
+        x = torch.randn(n, cs, generator=g).to(dev)
+        sh = torch.randn(cd, generator=g).to(dev)
+        for pair in (holes, none, sub.pair):
+            plan = ops.conv_plan(pair, sub.ld, 27, n)
+            for relu in (False, True):
+                ref = ops.conv_gemm(x, wp, cd, 27, pair, sub.ld, n, shift=sh, relu=relu)
+                outs = [ops.conv_gemm_balanced(x, wp, cd, 27, pair, sub.ld, n, plan, shift=sh, relu=relu) for _ in range(3)]
+                assert _rel_t(outs[0], ref) < 2e-6
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+        # rows of an empty super-tile are exactly epilogue(0)
+        plan = ops.conv_plan(holes, sub.ld, 27, n)
+        out = ops.conv_gemm_balanced(x, wp, cd, 27, holes, sub.ld, n, plan, shift=sh, relu=True)
+        assert torch.equal(out[128:320], torch.relu(sh).expand(192, cd))

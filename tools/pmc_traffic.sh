@@ -7,7 +7,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 400 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/$c.log 2>&1
+  timeout -k 5 400 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > $out/$c.log 2>&1
   echo "pass $c done"
 done
 python3 - <<PY

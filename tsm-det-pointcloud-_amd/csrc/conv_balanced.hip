@@ -15,8 +15,11 @@
 //      the next super-unit are gathered and the rule entries of the one after are read meanwhile; one barrier per
 //      super-unit.  A super-tile whose offsets all belong to one workgroup is written to `dst` directly; one shared with
 //      neighbouring workgroups goes to a scratch slot as a partial sum;
-//   3. k_conv_fixup adds the partial sums of every shared super-tile in workgroup order (= offset order, a fixed order)
-//      and applies the epilogue.  No atomics, no in-kernel hand-off: results are bitwise reproducible from run to run.
+//   3. the partial sums of a shared super-tile are combined INSIDE the launch: every owner draws a ticket from the tile's
+//      arrival counter (agent-scope release before, cdna_hip_programming.md §split-K recipe); the last arriver reads all
+//      partials back and adds them in workgroup order (= offset order, a FIXED order whoever arrives last), applies the
+//      epilogue and writes the rows.  No float atomics: results are bitwise reproducible from run to run.  (Round 1 did
+//      this in a second kernel, k_conv_fixup: 13 us + a launch gap per call.)
 // The plan depends only on the rule table, so the python layer caches it per rulebook (forward, dgrad and the second
 // layer of a submanifold pair all reuse it).
 //
@@ -45,11 +48,14 @@ constexpr int kLdsPerBlock = 36 * 1024;   // LDS footprint forced per workgroup:
 constexpr int kPreLds = 12 * 1024;  // prefix entries staged in LDS by the plan kernel (786k rows)
 constexpr int kHdr = 4;             // plan header: [0] active workgroups nb, [1] super-units U, [2] super-tiles T4, [3] -
 
-// plan layout (int32): hdr[kHdr] | wstart[kBlocks + 1, padded] | mask[4 * T4cap] | pre4[T4cap + 1]
+// plan layout (int32): hdr[kHdr] | wstart[kBlocks + 1, padded] | mask[4 * T4cap] | pre4[T4cap + 1] | arrivals[T4cap]
+// arrivals: per-super-tile ticket counters of the in-launch combine; zeroed by spx_conv_plan and reset by each last
+// arriver, so a plan serves any number of launches — one at a time (forward, dgrad, the sibling layer run in stream order).
 __host__ __device__ inline int64_t plan_off_wstart() { return kHdr; }
 __host__ __device__ inline int64_t plan_off_mask() { return kHdr + (kBlocks + 1 + 3) / 4 * 4; }   // 16-byte aligned
 __host__ __device__ inline int64_t plan_off_pre(int64_t t4cap) { return plan_off_mask() + kWpb * t4cap; }
-__host__ __device__ inline int64_t plan_ints(int64_t t4cap) { return plan_off_pre(t4cap) + t4cap + 1; }
+__host__ __device__ inline int64_t plan_off_arr(int64_t t4cap) { return plan_off_pre(t4cap) + t4cap + 1; }
+__host__ __device__ inline int64_t plan_ints(int64_t t4cap) { return plan_off_arr(t4cap) + t4cap; }
 
 // first super-unit of workgroup b when U super-units are dealt to nb workgroups
 __device__ __forceinline__ int block_u0(int b, int U, int nb) { return (int)((int64_t)b * U / nb); }
@@ -112,7 +118,10 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t n, const int64_t* d_
     __syncthreads();
     int off = s_carry;
     for (int i = 0; i < wv; ++i) off += s_wave[i];
-    if (S < T4) pre[S] = off + incl - v;
+    if (S < T4) {
+      pre[S] = off + incl - v;
+      plan[plan_off_arr(t4cap) + S] = 0;
+    }
     __syncthreads();
     if (tid == 1023) s_carry = off + incl;
     __syncthreads();
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t n, const int64_t* d_
     int nb = U / 8;                       // at least 8 super-units per workgroup
     if (nb > kBlocks) nb = kBlocks;
     if (nb >= 8) nb &= ~7;                // a multiple of 8: the XCD-contiguous numbering of the main kernel needs it
-    if (nb < 1) nb = U > 0 ? 1 : 0;
+    if (nb < 1) nb = 1;                   // also when U == 0: workgroup 0 still writes the empty super-tiles
     plan[0] = nb;
     plan[1] = U;
     plan[2] = T4;
@@ -154,6 +163,129 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t n, const int64_t* d_
   }
 }
 
+// ---------------------------------------------------------------- in-launch combine of shared super-tiles
+// owners of super-tile S = the workgroups whose unit range meets [p0, p0 + work): b_lo = last one starting at or before
+// p0, b_hi = last one starting before p0 + work
+__device__ __forceinline__ void tile_owners(int p0, int work, int U, int nb, int& b_lo, int& b_hi) {
+  int a = 0, b = nb - 1;
+  while (a < b) {
+    const int mid = (a + b + 1) >> 1;
+    if (block_u0(mid, U, nb) <= p0) a = mid; else b = mid - 1;
+  }
+  b_lo = a;
+  b = nb - 1;
+  while (a < b) {
+    const int mid = (a + b + 1) >> 1;
+    if (block_u0(mid, U, nb) < p0 + work) a = mid; else b = mid - 1;
+  }
+  b_hi = a;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Partial sums travel through `scratch` in the MFMA accumulator's own layout, slab[wave][nt][lane] = one f32x4 (rows
+// 16*wave + 4*(lane>>4) + e, column 16*nt + (lane&15)): every store and load is one coalesced 16-byte access per lane.
+// They are handed from workgroup to workgroup inside the launch, so (cdna_hip_programming.md §6 Guideline 16, R1) every
+// store is WRITE-THROUGH (`sc1`: no agent-scope release fence, which would write back the XCD's whole L2 once per
+// workgroup — measured: +25 us per launch), every storing wave drains its stores, the workgroup meets at a barrier, ONE
+// lane draws the tile's ticket with an agent-scope atomic; the workgroup that draws the last ticket acquires once
+// (invalidates its CU's L1) and reads every slab with `sc1` loads.
+__device__ __forceinline__ int slab_byte_off(int slot_index, int tile_floats, int NT, int wave, int nt, int lane) {
+  return (slot_index * (tile_floats / 4) + (wave * NT + nt) * 64 + lane) * 16;
+}
+
+// Called by ALL threads of a workgroup right after they stored their partial of shared super-tile S (sc1 stores).
+// Returns 0, or (b_lo | b_hi << 12) + 1 in the one workgroup that arrived last (then every partial of S is visible to it).
+// `flag` is one LDS word no wave is reading or writing at this point.
+__device__ __forceinline__ int tile_arrive(int S, int p0, int work, int U, int nb, int32_t* arrivals, volatile int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int b_lo, b_hi;
+    tile_owners(p0, work, U, nb, b_lo, b_hi);
+    const int t = __hip_atomic_fetch_add(&arrivals[S], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int f = 0;
+    if (t == b_hi - b_lo) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&arrivals[S], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      f = (b_lo | (b_hi << 12)) + 1;
+    }
+    *flag = f;
+  }
+  __syncthreads();
+  return *flag;
+}
+
+// last arriver: this wave's 16 rows of super-tile S = sum of the owners' partials in workgroup order (a fixed order,
+// whoever arrives last), epilogue, scatter through perm — the same code shape as the whole-tile write of the main loop
+template <int CD>
+__device__ __forceinline__ void tile_combine(int S, int owners, const int32_t* __restrict__ wstart,
+                                             __amdgpu_buffer_rsrc_t rs, int64_t nlive, const float* __restrict__ scale,
+                                             const float* __restrict__ shift, int relu, const int32_t* __restrict__ perm,
+                                             float* __restrict__ dst) {
+  constexpr int NT = CD / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+  const int b_lo = (owners - 1) & 0xFFF, b_hi = (owners - 1) >> 12;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = b_lo; b <= b_hi; ++b) {
+    const int slot = 2 * b + (wstart[b] == S ? 0 : 1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, slab_byte_off(slot, kRows * CD, NT, wave, nt, lane), 0, 16);
+      acc[nt] += __builtin_bit_cast(f32x4, u);
+    }
+  }
+  int64_t drow[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t orow = (int64_t)S * kRows + 16 * wave + 4 * q + e;
+    drow[e] = orow < nlive ? (perm ? (int64_t)perm[orow] : orow) : -1;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = 16 * nt + r;
+    const float sc = scale ? scale[col] : 1.0f;
+    const float sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (drow[e] >= 0) {
+        float v = acc[nt][e];
+        if (scale || shift) v = v * sc + sh;
+        if (relu) v = v > 0.f ? v : 0.f;
+        dst[drow[e] * CD + col] = v;
+      }
+    }
+  }
+}
+
+// super-tiles with no rule pair at all (possible on backward tables): rows = epilogue(0); dealt round-robin
+template <int CD, int NTHR>
+__device__ __forceinline__ void write_empty_tiles(int blk, int nb, int T4, const int32_t* __restrict__ pre, int64_t nlive,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                  int relu, const int32_t* __restrict__ perm, float* __restrict__ dst) {
+  constexpr int V = kRows * CD / 4;
+  for (int S = blk; S < T4; S += nb) {
+    if (pre[S + 1] != pre[S]) continue;
+    for (int i = threadIdx.x; i < V; i += NTHR) {
+      const int rr = (4 * i) / CD, c0 = (4 * i) % CD;
+      const int64_t orow = (int64_t)S * kRows + rr;
+      if (orow >= nlive) continue;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = shift ? shift[c0 + e] : 0.0f;
+        if (relu) x = x > 0.f ? x : 0.f;
+        v[e] = x;
+      }
+      const int64_t drow = perm ? (int64_t)perm[orow] : orow;
+      *reinterpret_cast<f32x4*>(dst + drow * CD + c0) = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- persistent, balanced, block-lockstep implicit GEMM
 template <int CS, int CD>
 __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv_mfma_pbl(const float* __restrict__ src, const float* __restrict__ wp,
@@ -162,11 +294,13 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
                                                        const float* __restrict__ shift, int relu,
                                                        const int32_t* __restrict__ plan, int64_t t4cap,
                                                        const int32_t* __restrict__ perm, float* __restrict__ dst,
-                                                       float* __restrict__ scratch) {
+                                                       float* __restrict__ scratch, int32_t* arrivals) {
   constexpr int NT = CD / 16;
   constexpr int JG = CS / 16;
   constexpr int NF = NT * JG;               // 1 KiB weight fragments per offset
-  __shared__ f32x4 sB[2][NF * 64];
+  __shared__ f32x4 sBF[2 * NF * 64 + 1];    // two weight buffers + one word for the "arrived last" broadcast (ONE object)
+  f32x4 (*sB)[NF * 64] = reinterpret_cast<f32x4 (*)[NF * 64]>(sBF);
+  volatile int* s_flag = reinterpret_cast<volatile int*>(&sBF[2 * NF * 64]);
   extern __shared__ char occupancy_pad[];   // tops the footprint up to kLdsPerBlock
   (void)occupancy_pad;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -188,6 +322,9 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
   const int u0 = block_u0(blk, U, nb), u1 = block_u0(blk + 1, U, nb);
   const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
   const int s_first = plan[plan_off_wstart() + blk];
+  const __amdgpu_buffer_rsrc_t rs_scratch =
+      __builtin_amdgcn_make_buffer_rsrc(scratch, 0, 2 * kBlocks * kRows * CD * (int)sizeof(float), 0x00020000);
+  write_empty_tiles<CD, 64 * kWpb>(blk, nb, T4, pre, nlive, scale, shift, relu, perm, dst);
 
   // ---- the workgroup's super-units in order (all values wave-uniform and equal in the four waves)
   struct Cur {
@@ -335,11 +472,14 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
       } else {
         // partial sums of a super-tile shared with neighbouring workgroups: slot 0 if it is this workgroup's first
         // super-tile, else slot 1
-        float* out = scratch + ((size_t)2 * blk + (c0.S == s_first ? 0 : 1)) * (kRows * CD) + (size_t)(16 * wave) * CD;
+        const int slot = 2 * blk + (c0.S == s_first ? 0 : 1);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) out[(4 * q + e) * CD + 16 * nt + r] = acc[nt][e];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nt]), rs_scratch,
+                                                 slab_byte_off(slot, kRows * CD, NT, wave, nt, lane), 0, 16);
+        const int p0 = pre[c0.S];
+        const int owners = tile_arrive(c0.S, p0, pre[c0.S + 1] - p0, U, nb, arrivals, s_flag);
+        if (owners) tile_combine<CD>(c0.S, owners, plan + plan_off_wstart(), rs_scratch, nlive, scale, shift, relu, perm, dst);
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -385,14 +525,16 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(2, 2)
     const float* __restrict__ src, const float* __restrict__ wp, const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
     int64_t n, const int64_t* d_n, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
     const int32_t* __restrict__ plan, int64_t t4cap, const int32_t* __restrict__ perm, float* __restrict__ dst,
-    float* __restrict__ scratch) {
+    float* __restrict__ scratch, int32_t* arrivals) {
   static_assert(kWpb == 4, "two-half kernel is written for 4 waves per workgroup");
   constexpr int NT = CD / 16;
   constexpr int NTH = NT / 2;               // column tiles per half
   constexpr int JG = CS / 16;
   constexpr int NF = NT * JG;               // 1 KiB weight fragments per offset
   constexpr int NFH = NTH * JG;             // per half
-  __shared__ f32x4 sB[2][NFH * 64];
+  __shared__ f32x4 sBF[2 * NFH * 64 + 1];   // two half-slice buffers + the "arrived last" word (ONE object)
+  f32x4 (*sB)[NFH * 64] = reinterpret_cast<f32x4 (*)[NFH * 64]>(sBF);
+  volatile int* s_flag = reinterpret_cast<volatile int*>(&sBF[2 * NFH * 64]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int nb = plan[0];
@@ -404,6 +546,9 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(2, 2)
   const int32_t* mask = plan + plan_off_mask();
   const int32_t* pre = plan + plan_off_pre(t4cap);
   const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+  const __amdgpu_buffer_rsrc_t rs_scratch =
+      __builtin_amdgcn_make_buffer_rsrc(scratch, 0, 2 * kBlocks * kRows * CD * (int)sizeof(float), 0x00020000);
+  write_empty_tiles<CD, 64 * kWpb>(lb, np, T4, pre, nlive, scale, shift, relu, perm, dst);
 
   for (int vv = 0; vv < 2; ++vv) {
     const int blk = 2 * lb + vv;            // virtual workgroup of the plan
@@ -530,11 +675,14 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(2, 2)
             }
           }
         } else {
-          float* out = scratch + ((size_t)2 * blk + (c0.S == s_first ? 0 : 1)) * (kRows * CD) + (size_t)(16 * wave) * CD;
+          const int slot = 2 * blk + (c0.S == s_first ? 0 : 1);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) out[(4 * q + e) * CD + 16 * nt + r] = acc[nt][e];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nt]), rs_scratch,
+                                                   slab_byte_off(slot, kRows * CD, NT, wave, nt, lane), 0, 16);
+          const int p0 = pre[c0.S];
+          const int owners = tile_arrive(c0.S, p0, pre[c0.S + 1] - p0, U, nb, arrivals, s_flag);
+          if (owners) tile_combine<CD>(c0.S, owners, plan + plan_off_wstart(), rs_scratch, nlive, scale, shift, relu, perm, dst);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -550,60 +698,6 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(2, 2)
   }
 }
 
-// ---------------------------------------------------------------- shared super-tiles: sum the partials in workgroup order
-template <int CD>
-__global__ __launch_bounds__(256) void k_conv_fixup(const int32_t* __restrict__ plan, int64_t t4cap, int64_t n,
-                                                    const int64_t* d_n, const float* __restrict__ scale,
-                                                    const float* __restrict__ shift, int relu,
-                                                    const int32_t* __restrict__ perm,
-                                                    const float* __restrict__ scratch, float* __restrict__ dst) {
-  constexpr int V = kRows * CD / 4;                    // float4 pieces per super-tile
-  const int nb = plan[0], U = plan[1], T4 = plan[2];
-  const int S = blockIdx.x;
-  if (S >= T4) return;
-  const int32_t* pre = plan + plan_off_pre(t4cap);
-  const int32_t* wstart = plan + plan_off_wstart();
-  const int p0 = pre[S], work = pre[S + 1] - p0;
-  int b_lo = 0, b_hi = -1;
-  if (work > 0) {
-    // workgroups whose range meets [p0, p0 + work): b_lo = last one starting at or before p0, b_hi = last one starting
-    // before p0 + work
-    int a = 0, b = nb - 1;
-    while (a < b) {
-      int mid = (a + b + 1) >> 1;
-      if (block_u0(mid, U, nb) <= p0) a = mid; else b = mid - 1;
-    }
-    b_lo = a;
-    a = b_lo, b = nb - 1;
-    while (a < b) {
-      int mid = (a + b + 1) >> 1;
-      if (block_u0(mid, U, nb) < p0 + work) a = mid; else b = mid - 1;
-    }
-    b_hi = a;
-    if (b_hi == b_lo) return;                          // one owner: written whole by the main kernel
-  }
-  const int64_t nlive = spx_live_n(d_n, n);
-  for (int i = threadIdx.x; i < V; i += 256) {
-    const int rr = (4 * i) / CD, c0 = (4 * i) % CD;
-    const int64_t orow = (int64_t)S * kRows + rr;
-    if (orow >= nlive) continue;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int b = b_lo; b <= b_hi; ++b) {
-      const int slot = wstart[b] == S ? 0 : 1;
-      v += reinterpret_cast<const f32x4*>(scratch + ((size_t)2 * b + slot) * (kRows * CD))[i];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x = v[e];
-      if (scale || shift) x = x * (scale ? scale[c0 + e] : 1.0f) + (shift ? shift[c0 + e] : 0.0f);
-      if (relu) x = x > 0.f ? x : 0.f;
-      v[e] = x;
-    }
-    const int64_t drow = perm ? (int64_t)perm[orow] : orow;
-    *reinterpret_cast<f32x4*>(dst + drow * CD + c0) = v;
-  }
-}
-
 static inline int64_t tiles4_cap(int64_t n) { return (n + kRows - 1) / kRows + 1; }
 
 template <int CS, int CD>
@@ -611,13 +705,11 @@ static void launch_pb(const float* src, const float* wp, const int32_t* pair, in
                       const int64_t* d_n, const float* scale, const float* shift, int relu, const int32_t* plan,
                       const int32_t* perm, float* dst, float* scratch, hipStream_t s) {
   const int64_t t4cap = tiles4_cap(n);
-  constexpr int kStatic = 2 * (CS / 16) * (CD / 16) * 1024;      // the two weight buffers
+  constexpr int kStatic = 2 * (CS / 16) * (CD / 16) * 1024 + 16;  // the two weight buffers + the flag word
   // (a 16-wave workgroup fills a CU's wave slots at this register count by itself: no padding needed)
   const int pad = (kWpb == 4 && kLdsPerBlock > kStatic) ? kLdsPerBlock - kStatic : 0;
   hipLaunchKernelGGL((k_conv_mfma_pbl<CS, CD>), dim3(kBlocks), dim3(64 * kWpb), pad, s, src, wp, pair, ld, K, flip, n, d_n, scale,
-                     shift, relu, plan, t4cap, perm, dst, scratch);
-  hipLaunchKernelGGL((k_conv_fixup<CD>), dim3((unsigned)((n + kRows - 1) / kRows)), dim3(256), 0, s, plan, t4cap, n, d_n, scale, shift,
-                     relu, perm, scratch, dst);
+                     shift, relu, plan, t4cap, perm, dst, scratch, const_cast<int32_t*>(plan) + plan_off_arr(t4cap));
 }
 
 template <int CS, int CD>
@@ -626,9 +718,7 @@ static void launch_pb2(const float* src, const float* wp, const int32_t* pair, i
                        const int32_t* perm, float* dst, float* scratch, hipStream_t s) {
   const int64_t t4cap = tiles4_cap(n);
   hipLaunchKernelGGL((k_conv_mfma_pbl2<CS, CD>), dim3(kBlocks / 2), dim3(64 * kWpb), 0, s, src, wp, pair, ld, K, flip, n, d_n,
-                     scale, shift, relu, plan, t4cap, perm, dst, scratch);
-  hipLaunchKernelGGL((k_conv_fixup<CD>), dim3((unsigned)((n + kRows - 1) / kRows)), dim3(256), 0, s, plan, t4cap, n, d_n, scale, shift,
-                     relu, perm, scratch, dst);
+                     scale, shift, relu, plan, t4cap, perm, dst, scratch, const_cast<int32_t*>(plan) + plan_off_arr(t4cap));
 }
 
 }  // namespace
@@ -665,7 +755,7 @@ extern "C" size_t spx_conv_gemm_balanced_ws_bytes(int c_dst, int64_t n_dst) {
 
 extern "C" int spx_conv_gemm_balanced(const float* src, int c_src, const float* w_packed, int c_dst, int kvol, int flip_k,
                                       const int32_t* pair, int64_t pair_ld, int64_t n_dst, const int64_t* d_n_dst,
-                                      const float* scale, const float* shift, int relu, const int32_t* plan,
+                                      const float* scale, const float* shift, int relu, int32_t* plan,
                                       const int32_t* perm, float* dst, void* ws, size_t ws_bytes, spx_stream_t stream) {
   if (!src || !w_packed || !pair || !dst || !plan || c_src <= 0 || c_dst <= 0 || kvol <= 0 || kvol > SPX_MAX_KVOL ||
       n_dst <= 0 || pair_ld < n_dst)

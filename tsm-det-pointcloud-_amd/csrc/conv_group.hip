@@ -7,6 +7,11 @@
 // 27-bit offset mask (stable: rows with equal masks keep the canonical order) and writes
 //   perm[j]          = table row processed at position j
 //   pair_grouped[k][j] = pair[k][perm[j]]          (-1 beyond the live rows)
+// Rows are grouped INSIDE EIGHT WINDOWS of the table (window = eighth of the live rows; sort key = window << 27 | mask):
+// the balanced kernel renumbers its workgroups so that each XCD walks a contiguous eighth of the work list, so with
+// windowed groups every XCD's private L2 gathers from its own eighth of the feature matrix (plus halo) instead of from
+// all of it — grouping over the whole table made each of the 8 L2s pull most of the matrix (fetch 2 x 106 MB per 82k-row
+// launch against 2 x 39 MB windowed, profiles/r01_conv_experiments.md).
 // spx_conv_plan / spx_conv_gemm_balanced then run over pair_grouped and scatter position j to dst row perm[j].  Every
 // output row is still the same sum over k in ascending order: values do not depend on the order of the rows.
 // The sort itself is rocPRIM's device radix sort (stable, deterministic); the kernels around it are below.
@@ -21,7 +26,9 @@ namespace {
 
 constexpr int kGR = 256;          // rows per workgroup
 constexpr int kRowInts = 32;      // row-major staging copy: one 128-byte line per row
-constexpr uint32_t kDeadKey = 1u << 30;   // sorts after every mask of kvol <= 30 bits
+constexpr uint32_t kDeadKey = 1u << 31;   // sorts after every (window, mask) key
+constexpr int kWindows = 8;               // one per XCD
+constexpr int kMaskBits = 27;             // kvol <= 27 keeps the window above the mask; larger kernels: one window
 
 // pass 1: key[row] = offset mask (dead rows last) and a row-major copy of the table, written through LDS so that both
 // the k-major reads and the row-major writes are coalesced.
@@ -31,6 +38,7 @@ __global__ __launch_bounds__(kGR) void k_group_keys(const int32_t* __restrict__ 
   __shared__ int32_t s[kRowInts][kGR + 1];
   const int64_t nlive = spx_live_n(d_n, n);
   const int64_t row0 = (int64_t)blockIdx.x * kGR, row = row0 + threadIdx.x;
+  const int64_t wsz = (nlive + kWindows - 1) / kWindows;
   uint32_t m = 0;
   for (int k = 0; k < kRowInts; ++k) {
     int32_t id = -1;
@@ -38,6 +46,7 @@ __global__ __launch_bounds__(kGR) void k_group_keys(const int32_t* __restrict__ 
     if (id >= 0) m |= 1u << k;
     s[k][threadIdx.x] = id;
   }
+  if (K <= kMaskBits && row < nlive) m |= (uint32_t)(row / (wsz > 0 ? wsz : 1)) << kMaskBits;
   if (row < n) key[row] = row < nlive ? m : kDeadKey;
   __syncthreads();
   for (int i = 0; i < kRowInts; ++i) {
@@ -93,7 +102,7 @@ static GroupWs group_layout(void* ws, int64_t n) {
   size_t tb = 0;
   // size query only: nothing is dereferenced or launched
   (void)rocprim::radix_sort_pairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  rocprim::counting_iterator<int32_t>(0), (int32_t*)nullptr, (size_t)n, 0u, 31u);
+                                  rocprim::counting_iterator<int32_t>(0), (int32_t*)nullptr, (size_t)n, 0u, 32u);
   L.temp_bytes = tb;
   L.temp = take(tb ? tb : 1);
   L.total = off;
@@ -119,7 +128,7 @@ extern "C" int spx_conv_group(const int32_t* pair, int64_t pair_ld, int kvol, in
   hipLaunchKernelGGL(k_group_keys, dim3(nblk), dim3(kGR), 0, s, pair, pair_ld, kvol, n_dst, d_n_dst, L.key_in, L.rowmajor);
   size_t tb = L.temp_bytes;
   if (rocprim::radix_sort_pairs(L.temp, tb, (const uint32_t*)L.key_in, L.key_out, rocprim::counting_iterator<int32_t>(0), perm,
-                                (size_t)n_dst, 0u, 31u, s) != hipSuccess)
+                                (size_t)n_dst, 0u, 32u, s) != hipSuccess)
     return SPX_ERR_LAUNCH;
   hipLaunchKernelGGL(k_group_permute, dim3(nblk), dim3(kGR), 0, s, L.rowmajor, perm, kvol, n_dst, d_n_dst, n_dst,
                      pair_grouped);
