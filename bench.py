@@ -427,7 +427,7 @@ def rulebook_rates(points, geom, batch, max_voxels, iters=30):
     idx, shape = vox["coords"], [int(gs[2]) + 1, int(gs[1]), int(gs[0])]
     strided = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
                ((3, 1, 1), (2, 1, 1), (0, 0, 0))]
-    out = {"subm": [], "strided": []}
+    out = {"subm_hash": [], "strided": [], "level": []}
 
     def ev_time(fn):
         for _ in range(3):
@@ -440,18 +440,21 @@ def rulebook_rates(points, geom, batch, max_voxels, iters=30):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / iters
 
-    for k, s, p in strided:
+    for j, (k, s, p) in enumerate(strided):
         n = idx.shape[0]
-        t = ev_time(lambda: ops.subm_rulebook(idx, batch, shape, (3, 3, 3)))
-        out["subm"].append((n, t))
+        if j == 0:     # level 1 rows arrive in voxeliser order: the one hash-built table of a forward pass
+            out["subm_hash"].append((n, ev_time(lambda: ops.subm_rulebook(idx, batch, shape, (3, 3, 3)))))
         rb = ops.conv_rulebook(idx, batch, shape, k, s, p)
-        t = ev_time(lambda: ops.conv_rulebook(idx, batch, shape, k, s, p, sync=False))
-        out["strided"].append((n, t))
+        out["strided"].append((n, ev_time(lambda: ops.conv_rulebook(idx, batch, shape, k, s, p, sync=False))))
+        if j < 3:      # strided tables + the submanifold table of the output level from the same rank bitmap, one call
+            t = ev_time(lambda: ops.conv_rulebook(idx, batch, shape, k, s, p, sync=False, subm_ksize=(3, 3, 3)))
+            out["level"].append((n + rb.n_out, t))
         idx, shape = rb.out_indices, rb.out_shape
-    res = {}
+    res = {"definition": "input voxels of the table(s) / build time (SURVEY.md 8d); level = strided tables of a stage + the "
+                         "submanifold table of its output level built in one call (n_in + n_out voxels)"}
     for kind, rows in out.items():
         res[kind] = round(sum(n for n, _t in rows) / sum(t for _n, t in rows) / 1e6, 1)
-        res[kind + "_tables"] = [{"n_in": n, "us": round(t * 1e6, 1), "mvoxels_s": round(n / t / 1e6, 1)} for n, t in rows]
+        res[kind + "_tables"] = [{"voxels": n, "us": round(t * 1e6, 1), "mvoxels_s": round(n / t / 1e6, 1)} for n, t in rows]
     return res
 
 

@@ -159,6 +159,11 @@ int spx_subm_rulebook(const int32_t *idx, int64_t n, const int64_t *d_n, int bat
  *                 overflow; a smaller static capacity is allowed (graph mode): rows beyond cap are dropped and
  *                 *d_n_out still reports the true count, so *d_n_out > cap signals overflow, and the status word
  *                 d_status (nullable, see spx_read_status) receives SPX_ERR_CAPACITY
+ *      subm_pair  (nullable) device [Ks, cap] int32: the SUBMANIFOLD table of the output level (section 2 semantics over
+ *                 out_idx, kernel subm_ksize / subm_dil, leading dimension cap) built from the same rank bitmap in the
+ *                 same call — the reference's stages are a strided conv followed by submanifold convs on its output
+ *                 (spconv_backbone.py:98-100,105-107,112-114), and the output rows are in rank order, so a neighbour
+ *                 lookup is one bitmap word + a popcount: no hash is built for that level.  subm_cnt: int32[Ks], nullable
  * ---------------------------------------------------------------------------------------------- */
 int64_t spx_conv_out_cap(int64_t n_in, int batch, const int32_t *out_shape, const int32_t *ksize,
                          const int32_t *stride);
@@ -166,7 +171,9 @@ size_t spx_conv_rulebook_ws_bytes(int64_t n_in, int batch, const int32_t *out_sh
 int spx_conv_rulebook(const int32_t *idx, int64_t n_in, const int64_t *d_n_in, int batch, const int32_t *in_shape,
                       const int32_t *out_shape, const int32_t *ksize, const int32_t *stride, const int32_t *pad,
                       const int32_t *dil, int32_t *out_idx, int32_t *pair_fwd, int32_t *pair_bwd, int32_t *cnt,
-                      int64_t *d_n_out, int64_t cap, int32_t *d_status, void *ws, size_t ws_bytes, spx_stream_t stream);
+                      int64_t *d_n_out, int64_t cap, const int32_t *subm_ksize, const int32_t *subm_dil,
+                      int32_t *subm_pair, int32_t *subm_cnt, int32_t *d_status, void *ws, size_t ws_bytes,
+                      spx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 4. Sparse convolution arithmetic

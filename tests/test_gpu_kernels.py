@@ -864,3 +864,69 @@ def test_conv_balanced_empty_tiles_and_combine(orc):
         plan = ops.conv_plan(holes, sub.ld, 27, n)
         out = ops.conv_gemm_balanced(x, wp, cd, 27, holes, sub.ld, n, plan, shift=sh, relu=True)
         assert torch.equal(out[128:320], torch.relu(sh).expand(192, cd))
+
+
+# ------------------------------------------------------------------------------------------ strided + submanifold tables in one build
+
+@pytest.mark.parametrize("cfg_id,nframes", [(1, 2), (2, 3)])
+def test_level_build_strided_plus_subm_from_bitmap(cfg_id, nframes, orc):
+    """spx_conv_rulebook with subm_ksize: the strided tables AND the submanifold table of the output level from one rank
+    bitmap (no hash), chained through the four levels of VoxelBackBone8x: everything bit-exact against the C oracle and
+    identical to the hash-built submanifold table; exact-size and static-capacity (device-side counts) forms."""
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, cfg_id, nframes)
+    dev = _dev()
+    chain = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1))]
+    for k, s, p in chain:
+        d_idx = torch.from_numpy(idx_np).to(dev)
+        rb = ops.conv_rulebook(d_idx, nframes, shape, k, s, p, want_cnt=True, subm_ksize=(3, 3, 3))
+        oi, pf, pb, cnt_o, oshape = orc.conv_rulebook(idx_np, shape, k, s, p)
+        assert rb.n_out == oi.shape[0] and rb.out_shape == oshape
+        assert np.array_equal(rb.out_indices.cpu().numpy(), oi)
+        assert np.array_equal(rb.pair[:, :rb.n_out].cpu().numpy(), pf)
+        assert np.array_equal(rb.pair_bwd.cpu().numpy(), pb)
+        assert np.array_equal(rb.cnt.cpu().numpy(), cnt_o)
+        sub = rb.subm_next
+        pair_o, scnt_o = orc.subm_rulebook(oi, oshape, (3, 3, 3))
+        assert sub.subm and sub.n_out == rb.n_out and sub.out_indices is rb.out_indices
+        assert np.array_equal(sub.pair[:, :sub.n_out].cpu().numpy(), pair_o)
+        assert np.array_equal(sub.cnt.cpu().numpy(), scnt_o)
+        hashed = ops.subm_rulebook(rb.out_indices, nframes, oshape, (3, 3, 3))
+        assert torch.equal(hashed.pair[:, :rb.n_out], sub.pair[:, :rb.n_out])
+        # static capacity: input at capacity with a device-side live count, output capped above the live count
+        n = idx_np.shape[0]
+        pad = torch.cat([d_idx, torch.full((257, 4), 7, dtype=torch.int32, device=dev)], 0)      # garbage rows beyond the live count
+        d_n = torch.tensor([n], dtype=torch.int64, device=dev)
+        rs = ops.conv_rulebook(pad, nframes, shape, k, s, p, d_n_in=d_n, cap=rb.n_out + 100, sync=False, subm_ksize=(3, 3, 3))
+        assert int(rs.d_n_out) == rb.n_out
+        assert np.array_equal(rs.out_indices[:rb.n_out].cpu().numpy(), oi)
+        assert np.array_equal(rs.pair[:, :rb.n_out].cpu().numpy(), pf)
+        assert np.array_equal(rs.pair_bwd[:, :n].cpu().numpy(), pb)
+        assert np.array_equal(rs.subm_next.pair[:, :rb.n_out].cpu().numpy(), pair_o)
+        idx_np, shape = oi, oshape
+
+
+def test_level_build_odd_strides_and_kernels(orc):
+    """Strides that are not powers of two (the integer-division form of the candidate test), anisotropic kernels,
+    dilation, a submanifold kernel other than 3x3x3, an empty input."""
+    from spx import ops
+    dev = _dev()
+    rs = np.random.RandomState(4)
+    shape = [13, 17, 19]
+    lin = np.sort(rs.permutation(2 * 13 * 17 * 19)[:1500])
+    idx_np = np.stack([lin // (13 * 17 * 19), (lin // (17 * 19)) % 13, (lin // 19) % 17, lin % 19], 1).astype(np.int32)
+    d_idx = torch.from_numpy(idx_np).to(dev)
+    for k, s, p, d, ks in (((3, 3, 3), (3, 3, 3), (1, 1, 1), (1, 1, 1), (3, 3, 3)), ((3, 2, 1), (1, 2, 3), (1, 0, 0), (1, 1, 1), (1, 3, 3)),
+                           ((2, 2, 2), (2, 2, 2), (0, 0, 0), (1, 1, 1), (3, 1, 1)), ((3, 3, 3), (2, 3, 1), (2, 2, 2), (2, 2, 2), (3, 3, 3))):
+        rb = ops.conv_rulebook(d_idx, 2, shape, k, s, p, d, want_cnt=True, subm_ksize=ks)
+        oi, pf, pb, cnt_o, oshape = orc.conv_rulebook(idx_np, shape, k, s, p, d)
+        assert np.array_equal(rb.out_indices.cpu().numpy(), oi) and rb.out_shape == oshape
+        assert np.array_equal(rb.pair[:, :rb.n_out].cpu().numpy(), pf)
+        assert np.array_equal(rb.pair_bwd.cpu().numpy(), pb)
+        assert np.array_equal(rb.cnt.cpu().numpy(), cnt_o)
+        pair_o, scnt_o = orc.subm_rulebook(oi, oshape, ks)
+        assert np.array_equal(rb.subm_next.pair[:, :rb.n_out].cpu().numpy(), pair_o)
+        assert np.array_equal(rb.subm_next.cnt.cpu().numpy(), scnt_o)
+    e = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    rb = ops.conv_rulebook(e, 1, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), subm_ksize=(3, 3, 3))
+    assert rb.n_out == 0 and rb.subm_next.n_out == 0

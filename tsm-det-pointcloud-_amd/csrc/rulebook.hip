@@ -109,18 +109,33 @@ __global__ void k_subm_probe(const int32_t* __restrict__ idx, int64_t n, const i
 
 struct ConvGeom {
   Int3 in_shape, out_shape, ks, stride, pad, dil;
+  Int3 ls;   // log2(stride) per axis, or -1: a run-time integer division is ~40 instructions, and the index kernels
+             // below are bound by exactly that arithmetic (every stride of the reference's backbones is 1 or 2)
 };
+
+// o = n / stride if divisible (n >= 0), else -1
+__device__ __forceinline__ int div_stride(int n, int s, int ls) {
+  if (ls >= 0) {
+    const int o = n >> ls;
+    return (o << ls) == n ? o : -1;
+  }
+  const int o = n / s;
+  return o * s == n ? o : -1;
+}
+
+// output coordinate along one axis of (input coordinate c, kernel index k), or -1
+__device__ __forceinline__ int cand_axis(int c, int k, const ConvGeom& g, int ax) {
+  const int n = c + g.pad.v[ax] - k * g.dil.v[ax];
+  if (n < 0) return -1;
+  const int o = div_stride(n, g.stride.v[ax], g.ls.v[ax]);
+  return o < g.out_shape.v[ax] ? o : -1;
+}
 
 // output linear key of (input voxel c, offset k) or -1
 __device__ __forceinline__ int64_t cand_key(const int4& c, int k, const ConvGeom& g) {
   int kx = k % g.ks.v[2], ky = (k / g.ks.v[2]) % g.ks.v[1], kz = k / (g.ks.v[2] * g.ks.v[1]);
-  int nz = c.y + g.pad.v[0] - kz * g.dil.v[0];
-  int ny = c.z + g.pad.v[1] - ky * g.dil.v[1];
-  int nx = c.w + g.pad.v[2] - kx * g.dil.v[2];
-  if (nz < 0 || ny < 0 || nx < 0) return -1;
-  int oz = nz / g.stride.v[0], oy = ny / g.stride.v[1], ox = nx / g.stride.v[2];
-  if (oz * g.stride.v[0] != nz || oy * g.stride.v[1] != ny || ox * g.stride.v[2] != nx) return -1;
-  if (oz >= g.out_shape.v[0] || oy >= g.out_shape.v[1] || ox >= g.out_shape.v[2]) return -1;
+  const int oz = cand_axis(c.y, kz, g, 0), oy = cand_axis(c.z, ky, g, 1), ox = cand_axis(c.w, kx, g, 2);
+  if ((oz | oy | ox) < 0) return -1;
   return spx_lin_key(c.x, oz, oy, ox, g.out_shape);
 }
 
@@ -129,15 +144,31 @@ __device__ __forceinline__ bool in_grid(const int4& c, int batch, const Int3& s)
          (unsigned)c.w < (unsigned)s.v[2];
 }
 
+// one thread per (input voxel, kz): the per-axis candidates are tested with shifts, and only the (ky, kx) combinations
+// that land on an output cell reach the atomic (3.4 of 27 on average at stride 2)
 __global__ void k_mark(const int32_t* __restrict__ idx, int64_t n, const int64_t* d_n, int batch, ConvGeom g,
                        uint64_t* bits) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= spx_live_n(d_n, n)) return;
   int4 c = reinterpret_cast<const int4*>(idx)[i];
   if (!in_grid(c, batch, g.in_shape)) return;
-  int64_t key = cand_key(c, blockIdx.y, g);
-  if (key < 0) return;
-  atomicOr(reinterpret_cast<unsigned long long*>(&bits[key >> 6]), 1ull << (key & 63));
+  {
+    const int kz = blockIdx.y;
+    const int oz = cand_axis(c.y, kz, g, 0);
+    if (oz < 0) return;
+    for (int ky = 0; ky < g.ks.v[1]; ++ky) {
+      const int oy = cand_axis(c.z, ky, g, 1);
+      if (oy < 0) continue;
+      for (int kx = 0; kx < g.ks.v[2]; ++kx) {
+        const int ox = cand_axis(c.w, kx, g, 2);
+        if (ox < 0) continue;
+        const int64_t key = spx_lin_key(c.x, oz, oy, ox, g.out_shape);
+        // (looking at the word first and skipping the atomic when the bit is already set — 62 % of the candidates at
+        // stride 2 — was measured SLOWER: 20.3 vs 14.7 us at 64k voxels; the atomic unit is not the bound)
+        atomicOr(reinterpret_cast<unsigned long long*>(&bits[key >> 6]), 1ull << (key & 63));
+      }
+    }
+  }
 }
 
 constexpr int kWordsPerThread = 1;   // one 64-cell word per thread: coalesced 8-byte loads, and the small dense grids of the deep levels (2-12 blocks at 8 words per thread, each thread decoding up to 8 x 64 cells serially: 30-48 us) spread over the chip
@@ -162,19 +193,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
   return base + inc - v;
 }
 
-__global__ void k_scan_blocksum(const uint64_t* __restrict__ bits, int64_t nwords, uint32_t* blocksum) {
-  int64_t w0 = (int64_t)blockIdx.x * kWordsPerBlock + (int64_t)threadIdx.x * kWordsPerThread;
-  uint32_t s = 0;
-#pragma unroll
-  for (int j = 0; j < kWordsPerThread; ++j)
-    if (w0 + j < nwords) s += __popcll(bits[w0 + j]);
-  uint32_t total;
-  block_exclusive_scan(s, &total);
-  if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
-}
-
-// single block: exclusive scan of blocksum in place, total -> d_n_out
-__global__ void k_scan_top(uint32_t* blocksum, int64_t nblk, int64_t* d_n_out, int64_t cap, int32_t* status) {
+// exclusive scan of blocksum[0..nblk) in place by ONE block, total -> *d_n_out (+ capacity check)
+__device__ __forceinline__ void scan_top_body(uint32_t* blocksum, int64_t nblk, int64_t* d_n_out, int64_t cap,
+                                              int32_t* status) {
   __shared__ uint32_t carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
@@ -194,6 +215,24 @@ __global__ void k_scan_top(uint32_t* blocksum, int64_t nblk, int64_t* d_n_out, i
     // more active cells than the caller's row capacity: rows beyond it are dropped — never silently
     if (status && (int64_t)carry_s > cap) atomicMin(status, (int32_t)SPX_ERR_CAPACITY);
   }
+}
+
+__global__ void k_scan_blocksum(const uint64_t* __restrict__ bits, int64_t nwords, uint32_t* blocksum) {
+  int64_t w0 = (int64_t)blockIdx.x * kWordsPerBlock + (int64_t)threadIdx.x * kWordsPerThread;
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < kWordsPerThread; ++j)
+    if (w0 + j < nwords) s += __popcll(bits[w0 + j]);
+  uint32_t total;
+  block_exclusive_scan(s, &total);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of blocksum in place, total -> d_n_out.  (Folding this into k_scan_blocksum through a
+// last-arriver ticket was tried: one ticket word drawn by ~3000 blocks serialises at the L2 atomic unit, 15.5 us against
+// 5 + 5.6 for the two launches.)
+__global__ void k_scan_top(uint32_t* blocksum, int64_t nblk, int64_t* d_n_out, int64_t cap, int32_t* status) {
+  scan_top_body(blocksum, nblk, d_n_out, cap, status);
 }
 
 __global__ void k_scan_expand(const uint64_t* __restrict__ bits, int64_t nwords, const uint32_t* __restrict__ blocksum,
@@ -258,16 +297,26 @@ __global__ void k_scan_expand(const uint64_t* __restrict__ bits, int64_t nwords,
   }
 }
 
-// pair_fwd[k][0..n_out) = -1, launched at capacity, guarded by the device-side count
+// rank of the active output cell `key` (row of the output tensor), or -1
+__device__ __forceinline__ int32_t rank_of(int64_t key, const uint64_t* __restrict__ bits, const uint32_t* __restrict__ prefix,
+                                           int64_t cap) {
+  const uint64_t w = bits[key >> 6];
+  const uint64_t bit = 1ull << (key & 63);
+  if (!(w & bit)) return -1;
+  const uint32_t r = prefix[key >> 6] + __popcll(w & (bit - 1));
+  return (int64_t)r < cap ? (int32_t)r : -1;
+}
+
+// pair_fwd[k][0..n_out) = -1 over the LIVE rows (grid-stride: the capacity can be several times the live count)
 __global__ void k_fill_neg1(int32_t* pair, int64_t ld, const int64_t* d_n_out) {
-  // grid-stride over the LIVE rows: the capacity is up to 8x the live count, and a grid sized by it was mostly blocks
-  // that exit at once (13-17 us per build)
   int64_t n = *d_n_out;
   if (n > ld) n = ld;
   for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (int64_t)gridDim.x * kBlock)
     pair[(int64_t)blockIdx.y * ld + o] = -1;
 }
 
+// Both tables of the strided conv, input-driven, one thread per (input voxel, offset): pair_bwd[k][i] = output row fed by
+// input i at offset k (coalesced along i) and the valid entries of pair_fwd[k][row] = i scattered over the -1 rows.
 __global__ void k_conv_pairs(const int32_t* __restrict__ idx, int64_t n, const int64_t* d_n, int batch, ConvGeom g,
                              const uint64_t* __restrict__ bits, const uint32_t* __restrict__ prefix,
                              int32_t* __restrict__ pair_fwd, int64_t cap, int32_t* __restrict__ pair_bwd,
@@ -280,8 +329,8 @@ __global__ void k_conv_pairs(const int32_t* __restrict__ idx, int64_t n, const i
     int4 c = reinterpret_cast<const int4*>(idx)[i];
     int64_t key = in_grid(c, batch, g.in_shape) ? cand_key(c, k, g) : -1;
     if (key >= 0) {
-      uint64_t w = bits[key >> 6];
-      uint32_t r = prefix[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1));
+      const uint64_t w = bits[key >> 6];                 // the cell is marked by construction: both loads are independent
+      const uint32_t r = prefix[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1));
       if ((int64_t)r < cap) {
         row = (int32_t)r;
         pair_fwd[(int64_t)k * cap + r] = (int32_t)i;
@@ -292,6 +341,53 @@ __global__ void k_conv_pairs(const int32_t* __restrict__ idx, int64_t n, const i
   if (cnt != nullptr) {
     unsigned long long m = __ballot(row >= 0);
     if (spx_lane() == 0 && m) atomicAdd(&cnt[k], __popcll(m));
+  }
+}
+
+// Submanifold table of the OUTPUT level from the same bitmap: its rows are in rank order (= canonical key order), so the
+// neighbour at offset k of row o is rank_of(key(coord(o) + (k - centre) * dil)) — one word load + one popcount instead of
+// a hash probe, and no hash build at all.  grid (ceil(cap / 256), KZ * KY): a thread resolves the KX neighbours of one
+// (kz, ky) line, which sit in one bitmap word (two at a word boundary); rows of one offset contiguous -> coalesced stores.
+__global__ void k_subm_from_bitmap(const int32_t* __restrict__ out_idx, const int64_t* __restrict__ d_n_out, int64_t cap,
+                                   Int3 shape, Int3 ks, Int3 dil, const uint64_t* __restrict__ bits,
+                                   const uint32_t* __restrict__ prefix, int32_t* __restrict__ pair, int64_t ld,
+                                   int32_t* cnt) {
+  const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int ky = blockIdx.y % ks.v[1], kz = blockIdx.y / ks.v[1];
+  int64_t nlive = *d_n_out;
+  if (nlive > cap) nlive = cap;
+  const bool live = o < nlive;
+  int4 c = make_int4(0, 0, 0, 0);
+  if (live) c = reinterpret_cast<const int4*>(out_idx)[o];
+  const int z = c.y + (kz - ks.v[0] / 2) * dil.v[0];
+  const int y = c.z + (ky - ks.v[1] / 2) * dil.v[1];
+  const bool line_ok = live && (unsigned)z < (unsigned)shape.v[0] && (unsigned)y < (unsigned)shape.v[1];
+  const int64_t line_key = line_ok ? spx_lin_key(c.x, z, y, 0, shape) : 0;
+  int64_t w_cached = -1;
+  uint64_t w_bits = 0;
+  uint32_t w_pre = 0;
+  for (int kx = 0; kx < ks.v[2]; ++kx) {
+    const int k = (kz * ks.v[1] + ky) * ks.v[2] + kx;
+    const int x = c.w + (kx - ks.v[2] / 2) * dil.v[2];
+    int32_t r = -1;
+    if (line_ok && (unsigned)x < (unsigned)shape.v[2]) {
+      const int64_t key = line_key + x;
+      if ((key >> 6) != w_cached) {
+        w_cached = key >> 6;
+        w_bits = bits[w_cached];
+        w_pre = prefix[w_cached];
+      }
+      const uint64_t bit = 1ull << (key & 63);
+      if (w_bits & bit) {
+        const uint32_t rr = w_pre + __popcll(w_bits & (bit - 1));
+        if ((int64_t)rr < cap) r = (int32_t)rr;
+      }
+    }
+    if (live) pair[(int64_t)k * ld + o] = r;
+    if (cnt != nullptr) {
+      const unsigned long long m = __ballot(r >= 0);
+      if (spx_lane() == 0 && m) atomicAdd(&cnt[k], __popcll(m));
+    }
   }
 }
 
@@ -349,11 +445,12 @@ extern "C" int64_t spx_conv_out_cap(int64_t n_in, int batch, const int32_t* out_
 
 namespace {
 struct RbWs {
-  uint64_t* bits;
+  uint64_t* bits;       // [nwords]  (+ the scan ticket right behind it: one fill clears both)
+  uint32_t* ticket;
   uint32_t* prefix;
   uint32_t* blocksum;
   int64_t nwords, nblk;
-  size_t total;
+  size_t total, clear_bytes;
 };
 static RbWs rb_layout(void* ws, int batch, const int32_t* out_shape) {
   RbWs r;
@@ -363,13 +460,20 @@ static RbWs rb_layout(void* ws, int batch, const int32_t* out_shape) {
   char* p = reinterpret_cast<char*>(ws);
   size_t o = 0;
   r.bits = reinterpret_cast<uint64_t*>(p + o);
-  o += spx_align((size_t)r.nwords * 8);
+  r.ticket = reinterpret_cast<uint32_t*>(p + o + (size_t)r.nwords * 8);
+  r.clear_bytes = (size_t)r.nwords * 8 + 16;
+  o += spx_align(r.clear_bytes);
   r.prefix = reinterpret_cast<uint32_t*>(p + o);
   o += spx_align((size_t)r.nwords * 4);
   r.blocksum = reinterpret_cast<uint32_t*>(p + o);
   o += spx_align((size_t)(r.nblk + 1) * 4);
   r.total = o;
   return r;
+}
+static inline int log2_or_neg(int v) {
+  for (int l = 0; l < 31; ++l)
+    if ((1 << l) == v) return l;
+  return -1;
 }
 }  // namespace
 
@@ -382,6 +486,7 @@ extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t
                                  const int32_t* in_shape, const int32_t* out_shape, const int32_t* ksize,
                                  const int32_t* stride, const int32_t* pad, const int32_t* dil, int32_t* out_idx,
                                  int32_t* pair_fwd, int32_t* pair_bwd, int32_t* cnt, int64_t* d_n_out, int64_t cap,
+                                 const int32_t* subm_ksize, const int32_t* subm_dil, int32_t* subm_pair, int32_t* subm_cnt,
                                  int32_t* d_status, void* ws, size_t ws_bytes, spx_stream_t stream) {
   if ((!idx && n_in > 0) || !in_shape || !out_shape || !ksize || !stride || !pad || !dil || !out_idx || !pair_fwd || !pair_bwd ||
       !d_n_out || n_in < 0 || batch <= 0 || cap <= 0)
@@ -392,6 +497,12 @@ extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t
     if (stride[j] <= 0 || dil[j] <= 0 || pad[j] < 0 || in_shape[j] <= 0) return SPX_ERR_INVALID_ARG;
     int expect = (in_shape[j] + 2 * pad[j] - dil[j] * (ksize[j] - 1) - 1) / stride[j] + 1;
     if (out_shape[j] != expect || expect <= 0) return SPX_ERR_INVALID_ARG;
+  }
+  int Ks = 0;
+  if (subm_pair) {
+    if (!subm_ksize || !subm_dil) return SPX_ERR_INVALID_ARG;
+    Ks = subm_ksize[0] * subm_ksize[1] * subm_ksize[2];
+    if (Ks <= 0 || Ks > SPX_MAX_KVOL || subm_dil[0] <= 0 || subm_dil[1] <= 0 || subm_dil[2] <= 0) return SPX_ERR_INVALID_ARG;
   }
   if (n_in >= (int64_t(1) << 31) || cap >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
   if (cells_of(batch, out_shape) >= (int64_t(1) << 40)) return SPX_ERR_TOO_LARGE;
@@ -407,20 +518,30 @@ extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t
   g.stride = spx_i3(stride);
   g.pad = spx_i3(pad);
   g.dil = spx_i3(dil);
+  for (int j = 0; j < 3; ++j) g.ls.v[j] = log2_or_neg(stride[j]);
+  // 8 launches for the strided tables AND the submanifold table of the output level (round 1: 8 + 4):
+  //   clear bitmap (+ counters) ; mark ; block sums ; top scan ; ranks + out indices ; -1 over the live rows of the
+  //   forward table ; pair tables ; submanifold table (no hash build, no probe kernel for that level)
   if (cnt) spx_fill_async(cnt, 0, sizeof(int32_t) * K, s);
-  spx_fill_async(w.bits, 0, (size_t)w.nwords * 8, s);
+  if (subm_cnt) spx_fill_async(subm_cnt, 0, sizeof(int32_t) * Ks, s);
+  spx_fill_async(w.bits, 0, w.clear_bytes, s);
   unsigned nb_in = (unsigned)((n_in + kBlock - 1) / kBlock);
-  if (n_in > 0) hipLaunchKernelGGL(k_mark, dim3(nb_in, K), dim3(kBlock), 0, s, idx, n_in, d_n_in, batch, g, w.bits);
+  if (n_in > 0)
+    hipLaunchKernelGGL(k_mark, dim3(nb_in, (unsigned)ksize[0]), dim3(kBlock), 0, s, idx, n_in, d_n_in, batch, g, w.bits);
   hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, w.blocksum, w.nblk, d_n_out, cap, d_status);
   hipLaunchKernelGGL(k_scan_expand, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum, w.prefix,
                      g.out_shape, out_idx, cap);
   unsigned nb_cap = (unsigned)((cap + kBlock - 1) / kBlock);
-  if (nb_cap > 256) nb_cap = 256;
-  hipLaunchKernelGGL(k_fill_neg1, dim3(nb_cap, K), dim3(kBlock), 0, s, pair_fwd, cap, d_n_out);
+  hipLaunchKernelGGL(k_fill_neg1, dim3(nb_cap > 256 ? 256 : nb_cap, K), dim3(kBlock), 0, s, pair_fwd, cap, d_n_out);
   if (n_in > 0)
     hipLaunchKernelGGL(k_conv_pairs, dim3(nb_in, K), dim3(kBlock), 0, s, idx, n_in, d_n_in, batch, g, w.bits, w.prefix,
                        pair_fwd, cap, pair_bwd, cnt);
+  if (subm_pair)
+    hipLaunchKernelGGL(k_subm_from_bitmap, dim3((unsigned)((cap + kBlock - 1) / kBlock), (unsigned)(subm_ksize[0] * subm_ksize[1])),
+                       dim3(kBlock), 0, s, out_idx,
+                       d_n_out, cap, g.out_shape, spx_i3(subm_ksize), spx_i3(subm_dil), w.bits, w.prefix, subm_pair, cap,
+                       subm_cnt);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }
@@ -560,7 +681,7 @@ static DynWs dyn_layout(void* ws, int64_t n, int batch, const int32_t* grid, int
   char* p = reinterpret_cast<char*>(ws);
   size_t o = 0;
   r.bits = reinterpret_cast<uint64_t*>(p + o);
-  o += spx_align((size_t)r.nwords * 8);
+  o += spx_align((size_t)r.nwords * 8 + 16);          // + the scan ticket
   r.prefix = reinterpret_cast<uint32_t*>(p + o);
   o += spx_align((size_t)r.nwords * 4);
   r.blocksum = reinterpret_cast<uint32_t*>(p + o);
@@ -607,14 +728,15 @@ extern "C" int spx_dynamic_voxelize(const float* points, int64_t n_points, int s
     g.vs[j] = voxel_size3[j];
     g.grid[j] = grid3[j];
   }
-  spx_fill_async(w.bits, 0, (size_t)w.nwords * 8, s);
+  spx_fill_async(w.bits, 0, (size_t)w.nwords * 8 + 16, s);                     // bitmap + scan ticket
   spx_fill_async(w.count, 0, (size_t)((char*)w.offset - (char*)w.count), s);   // count + cursor
   const unsigned nbp = (unsigned)((n_points + kBlock - 1) / kBlock);
   if (n_points > 0)
     hipLaunchKernelGGL(k_dyn_mark, dim3(nbp), dim3(kBlock), 0, s, points, n_points, stride, batch_col, xyz_col, batch, g,
                        w.bits, w.keys);
   hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, w.blocksum, w.nblk, d_num_voxels, cap, (int32_t*)nullptr);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, w.blocksum, w.nblk, d_num_voxels, (int64_t(1) << 62),
+                     (int32_t*)nullptr);
   Int3 shape;
   shape.v[0] = grid3[0], shape.v[1] = grid3[1], shape.v[2] = grid3[2];
   hipLaunchKernelGGL(k_scan_expand, dim3((unsigned)w.nblk), dim3(kBlock), 0, s, w.bits, w.nwords, w.blocksum, w.prefix, shape,

@@ -43,7 +43,7 @@ SIGNATURES = {
     "spx_conv_out_cap": (_i64, [_i64, _int, _i32p, _i32p, _i32p]),
     "spx_conv_rulebook_ws_bytes": (_sz, [_i64, _int, _i32p]),
     "spx_conv_rulebook": (_int, [_vp, _i64, _vp, _int, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _vp, _vp, _vp, _vp,
-                                 _vp, _i64, _vp, _vp, _sz, _vp]),
+                                 _vp, _i64, _i32p, _i32p, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spx_pack_weight": (_int, [_vp, _int, _int, _int, _int, _vp, _vp]),
     "spx_conv_gemm": (_int, [_vp, _int, _vp, _int, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp]),
     "spx_conv_plan_bytes": (_sz, [_i64]),

@@ -221,8 +221,9 @@ def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1),
 
 
 def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1), want_cnt=False,
-                  d_n_in=None, cap=None, sync=True):
-    """Regular sparse conv rulebook.  sync=True: one host sync (reads n_out), exact-size out_indices; sync="later": a
+                  d_n_in=None, cap=None, sync=True, subm_ksize=None, subm_dilation=(1, 1, 1)):
+    """Regular sparse conv rulebook.  subm_ksize: also build the SUBMANIFOLD table of the output level from the same rank
+    bitmap (no hash for that level); it comes back as `rb.subm_next` (a Rulebook over rb.out_indices).  sync=True: one host sync (reads n_out), exact-size out_indices; sync="later": a
     PendingRulebook whose .finish() does that read.
     sync=False (static-capacity / graph mode): no sync; `cap` output rows (default: the no-overflow bound), live counts
     in rb.d_n_in / rb.d_n_out; rows beyond cap are dropped (overflow <=> rb.d_n_out > cap)."""
@@ -241,29 +242,44 @@ def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, di
     pair_bwd = torch.empty((K, max(n_in, 1)), dtype=torch.int32, device=dev)
     cnt = torch.empty((K,), dtype=torch.int32, device=dev) if want_cnt else None   # zeroed by the library
     d_n = torch.zeros((1,), dtype=torch.int64, device=dev)
+    Ks = 0 if subm_ksize is None else int(subm_ksize[0]) * int(subm_ksize[1]) * int(subm_ksize[2])
+    subm_pair = torch.empty((Ks, cap), dtype=torch.int32, device=dev) if Ks else None
+    subm_cnt = torch.empty((Ks,), dtype=torch.int32, device=dev) if (Ks and want_cnt) else None
     wsb = lib.spx_conv_rulebook_ws_bytes(n_in, batch_size, i3(out_shape))
     ws = workspace(dev, wsb)
     # a capacity below the no-overflow bound can drop rows: the kernels say so in the sticky status word (check_status)
     d_st = _ptr(status_word(dev)) if cap < safe_cap else None
     check(lib.spx_conv_rulebook(_ptr(indices), n_in, _ptr(d_n_in), batch_size, i3(spatial_shape), i3(out_shape), i3(ksize),
                                 i3(stride), i3(padding), i3(dilation), _ptr(out_idx), _ptr(pair_fwd), _ptr(pair_bwd),
-                                _ptr(cnt), _ptr(d_n), cap, d_st, _ptr(ws), wsb, _stream(indices)), "spx_conv_rulebook")
+                                _ptr(cnt), _ptr(d_n), cap, i3(subm_ksize) if Ks else None,
+                                i3(subm_dilation) if Ks else None, _ptr(subm_pair), _ptr(subm_cnt), d_st, _ptr(ws), wsb,
+                                _stream(indices)), "spx_conv_rulebook")
+
+    def with_subm(rb):
+        if Ks:
+            n = rb.n_out
+            nxt = Rulebook(subm_pair, cap, n, n, Ks, True, rb.out_indices, out_shape, out_shape, cnt=subm_cnt,
+                           ksize=list(subm_ksize), stride=[1, 1, 1], padding=[k // 2 for k in subm_ksize],
+                           dilation=list(subm_dilation))
+            nxt.d_n_in = nxt.d_n_out = rb.d_n_out
+            rb.subm_next = nxt
+        return rb
     if not sync:
         rb = Rulebook(pair_fwd, cap, n_in, cap, K, False, out_idx, out_shape, spatial_shape, pair_bwd=pair_bwd, cnt=cnt,
                       ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation))
         rb.d_n_in, rb.d_n_out = d_n_in, d_n
-        return rb
+        return with_subm(rb)
     if sync == "later":
         # The row count is read back asynchronously; .finish() waits for it.  A caller that launches this table one stage
         # early (before it queues the previous stage's kernels) finds the count already there: the host never waits on an
         # empty GPU (pcdet_amd/models/backbones_3d/spconv_backbone.py).
-        return PendingRulebook(d_n, lambda n_out: Rulebook(
+        return PendingRulebook(d_n, lambda n_out: with_subm(Rulebook(
             pair_fwd, cap, n_in, n_out, K, False, out_idx[:n_out], out_shape, spatial_shape, pair_bwd=pair_bwd, cnt=cnt,
-            ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation)))
+            ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation))))
     n_out = int(d_n.item())
     rb = Rulebook(pair_fwd, cap, n_in, n_out, K, False, out_idx[:n_out], out_shape, spatial_shape, pair_bwd=pair_bwd,
                   cnt=cnt, ksize=list(ksize), stride=list(stride), padding=list(padding), dilation=list(dilation))
-    return rb
+    return with_subm(rb)
 
 
 class PendingRulebook(object):

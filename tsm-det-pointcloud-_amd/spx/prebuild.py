@@ -63,18 +63,29 @@ def prebuild(x, convs, backward=None):
     caps = x.static_caps or {}
     with torch.cuda.stream(side):
         idx, shape, d_n = x.indices, x.spatial_shape, x.n_valid
-        for m in convs:
+        pending = {}                       # submanifold tables that came out of a strided build (same rank bitmap)
+        for pos, m in enumerate(convs):
             key = m.indice_key
             if key is None or m.inverse:
                 continue
             rb = x.indice_dict.get(key)
             if rb is None:
                 if m.subm:
-                    rb = ops.subm_rulebook(idx, x.batch_size, shape, m.kernel_size, m.dilation, d_n=d_n)
+                    rb = pending.pop(key, None)
+                    if rb is None:
+                        rb = ops.subm_rulebook(idx, x.batch_size, shape, m.kernel_size, m.dilation, d_n=d_n)
                 else:
+                    # the first not-yet-built submanifold conv after this one works on this conv's output level
+                    nxt = next((c for c in convs[pos + 1:] if not c.inverse and c.indice_key is not None
+                                and c.indice_key not in x.indice_dict), None)
+                    want = nxt is not None and nxt.subm
                     rb = ops.conv_rulebook(idx, x.batch_size, shape, m.kernel_size, m.stride, m.padding, m.dilation,
-                                           d_n_in=d_n, cap=caps.get(key), sync=False)
+                                           d_n_in=d_n, cap=caps.get(key), sync=False,
+                                           subm_ksize=nxt.kernel_size if want else None,
+                                           subm_dilation=nxt.dilation if want else (1, 1, 1))
                     rb.in_indices = idx
+                    if want:
+                        pending[nxt.indice_key] = rb.subm_next
                 for u in users[key]:
                     _plans(rb, u, backward)
                 rb.ready = torch.cuda.Event()
