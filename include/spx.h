@@ -338,6 +338,14 @@ int spx_bn_add_relu_bwd(const float *x, const float *res, const float *dy, int64
                         float *dx, float *dres, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
                         spx_stream_t stream);
 
+/* Inference-mode BatchNorm (+ residual) (+ ReLU) with GIVEN statistics, one pass: y = relu?((x - mean) * invstd * gamma + beta
+ * (+ res)).  replaces: nn.BatchNorm2d (eval) + nn.ReLU of the BEV backbone, reference
+ * pcdet/models/backbones_2d/base_bev_backbone.py:35-44,60-73 (two elementwise passes in torch), applied to the channels_last
+ * map as [B*H*W, C] rows; y_ld as in spx_bn_add_relu_fwd (a channel slice of the concatenated map, :99-106). */
+int spx_bn_apply(const float *x, const float *res, int64_t n, const int64_t *d_n, int c, const float *mean,
+                 const float *invstd, const float *gamma, const float *beta, int relu, float *y, int64_t y_ld,
+                 spx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 10. Voxel query (consumers of multi_scale_3d_features)
  *    replaces: pointnet2_stack_cuda.voxel_query_wrapper, reference

@@ -698,3 +698,38 @@ def test_static_capacity_overflow_is_reported():
     with pytest.raises(_lib.SpxError, match="static row capacity"):
         ops.check_status(dev)
     ops.check_status(dev)
+
+
+def test_bev_eval_fused_bn_relu_and_cat_match_plain_modules():
+    """Inference route of BaseBEVBackbone: BatchNorm2d on running statistics + ReLU as ONE libspx pass over the channels_last
+    rows (spx_bn_apply), the up-sampling branches written straight into the slices of the concatenated map — against the
+    plain torch modules of the same network (the fused routes switched off): every output map within 2e-6."""
+    from pcdet_amd.config import AttrDict
+    from pcdet_amd.models.backbones_2d import base_bev_backbone as bb
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    cfg = AttrDict(dict(LAYER_NUMS=[2, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[64, 128], UPSAMPLE_STRIDES=[1, 2],
+                        NUM_UPSAMPLE_FILTERS=[128, 128]))
+    net = bb.BaseBEVBackbone(cfg, 64).to(dev).to(memory_format=torch.channels_last).eval()
+    g = torch.Generator().manual_seed(5)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+    x = torch.randn(2, 64, 48, 40, device=dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        fused = net({"spatial_features": x})
+        old = bb._FUSED_EVAL_BN
+        bb._FUSED_EVAL_BN = False
+        try:
+            plain = net({"spatial_features": x})
+        finally:
+            bb._FUSED_EVAL_BN = old
+    for k in ("spatial_features_2d", "spatial_features_1x", "spatial_features_2x"):
+        assert fused[k].shape == plain[k].shape
+        assert _rel(fused[k], plain[k]) < 2e-6, k
+    assert fused["spatial_features_2d"].shape == (2, 256, 48, 40)
+    assert fused["spatial_features_2d"].is_contiguous(memory_format=torch.channels_last)
+    assert float(fused["spatial_features_2d"].min()) >= 0.0

@@ -291,3 +291,20 @@ extern "C" int spx_bn_relu_bwd(const float* x, const float* dy, int64_t n, const
   return spx_bn_add_relu_bwd(x, nullptr, dy, c, n, d_n, c, gamma, beta, save_mean, save_invstd, relu, dx, nullptr, dgamma, dbeta, ws,
                              ws_bytes, stream);
 }
+
+// Inference-mode BatchNorm (+ residual) (+ ReLU) over feature rows: y = relu?((x - mean) * invstd * gamma + beta (+ res)) with
+// GIVEN statistics (the running estimates), one read and one write — nn.BatchNorm2d(eval) + nn.ReLU of the BEV backbone
+// (reference base_bev_backbone.py:35-44,60-73) are two passes in torch.  Same row-strided output as the training kernels.
+extern "C" int spx_bn_apply(const float* x, const float* res, int64_t n, const int64_t* d_n, int c, const float* mean,
+                            const float* invstd, const float* gamma, const float* beta, int relu, float* y, int64_t y_ld,
+                            spx_stream_t stream) {
+  if (!x || !mean || !invstd || !gamma || !beta || !y || n < 0 || c <= 0) return SPX_ERR_INVALID_ARG;
+  if (c % 4 != 0 || 1024 % c != 0) return SPX_ERR_UNSUPPORTED;
+  if (y_ld == 0) y_ld = c;
+  if (y_ld < c || y_ld % 4 != 0 || ((uintptr_t)y & 15) != 0) return SPX_ERR_INVALID_ARG;
+  if (n == 0) return SPX_OK;
+  hipLaunchKernelGGL(k_bn_apply, dim3(bn_blocks(n, c)), dim3(256), 0, spx_s(stream), x, mean, invstd, gamma, beta, n, d_n, c,
+                     relu, res, y_ld, log2_of(c), y);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}

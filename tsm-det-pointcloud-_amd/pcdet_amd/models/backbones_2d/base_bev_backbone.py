@@ -43,9 +43,32 @@ def _run_block(seq, x, start=0):
             x = y.view(b, h, w, c).permute(0, 3, 1, 2)
             i += 2
             continue
+        if _eval_bn_ok(m, x) and isinstance(nxt, nn.ReLU):
+            b, c, h, w = x.shape
+            y = _bn_eval_rows(x.permute(0, 2, 3, 1).reshape(b * h * w, c), m, True)
+            x = y.view(b, h, w, c).permute(0, 3, 1, 2)
+            i += 2
+            continue
         x = m(x)
         i += 1
     return x
+
+
+_FUSED_EVAL_BN = os.environ.get("SPX_BEV_FUSED_EVAL_BN", "1") != "0"       # dev knob
+
+
+def _eval_bn_ok(m, x):
+    """Inference: BatchNorm2d on running statistics + ReLU over a channels_last fp32 map = ONE libspx pass over its
+    [B*H*W, C] rows (spx_bn_apply) instead of two torch elementwise passes."""
+    return (_FUSED_EVAL_BN and isinstance(m, nn.BatchNorm2d) and not m.training and m.affine and m.running_mean is not None
+            and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and not torch.is_autocast_enabled() and 1024 % x.shape[1] == 0 and x.shape[1] % 4 == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _bn_eval_rows(rows, bn, relu, out=None):
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    return ops.bn_apply(rows, bn.running_mean, invstd, bn.weight, bn.bias, relu, out=out)
 
 
 _SPARSE_ENTRY = os.environ.get("SPX_BEV_SPARSE_ENTRY", "1") != "0"     # dev knob
@@ -160,26 +183,47 @@ class BaseBEVBackbone(nn.Module):
                 return False
         return True
 
+    def _cat_eval_fusable(self, x):
+        """Inference twin of _cat_fusable: every up-sampling branch is conv, BatchNorm2d (running statistics), ReLU."""
+        if not _FUSED_EVAL_BN or len(self.deblocks) != len(self.blocks) or len(self.deblocks) < 2 or torch.is_grad_enabled():
+            return False
+        return all(len(d) == 3 and isinstance(d[1], nn.BatchNorm2d) and isinstance(d[2], nn.ReLU) and not d[1].training
+                   and d[1].affine and d[1].running_mean is not None and 1024 % d[1].num_features == 0
+                   and d[1].num_features % 4 == 0 for d in self.deblocks)
+
     def forward(self, data_dict):
         spatial_features = data_dict['spatial_features']
         ups, pre = [], []
         x = spatial_features
-        fuse_cat = self._cat_fusable() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+        plain = x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+        fuse_cat = self._cat_fusable() and plain
+        fuse_cat_eval = (not fuse_cat) and plain and self._cat_eval_fusable(x)
         for i in range(len(self.blocks)):
             y = _sparse_entry(self.blocks[i], x) if i == 0 else None
             x = _run_block(self.blocks[i], x) if y is None else _run_block(self.blocks[i], y, start=2)
             stride = int(spatial_features.shape[2] / x.shape[2])
             data_dict['spatial_features_%dx' % stride] = x
-            if fuse_cat:
+            if fuse_cat or fuse_cat_eval:
                 pre.append(self.deblocks[i][0](x))                      # the up-sampling conv; BN + ReLU follow below
             else:
                 ups.append(_run_block(self.deblocks[i], x) if len(self.deblocks) > 0 else x)
-        if fuse_cat:
+        if fuse_cat or fuse_cat_eval:
             b, _c, h, w = pre[0].shape
-            if all(t.shape[0] == b and t.shape[2:] == pre[0].shape[2:] and t.numel() >= _FUSED_BN_MIN_ELEMS
-                   and t.is_contiguous(memory_format=torch.channels_last) for t in pre):
+            same = all(t.shape[0] == b and t.shape[2:] == pre[0].shape[2:]
+                       and t.is_contiguous(memory_format=torch.channels_last) for t in pre)
+            if same and fuse_cat and all(t.numel() >= _FUSED_BN_MIN_ELEMS for t in pre):
                 rows = [t.permute(0, 2, 3, 1).reshape(b * h * w, t.shape[1]) for t in pre]
                 y = bn_relu_cat_train(rows, [d[1] for d in self.deblocks])
+                ups = [y.view(b, h, w, y.shape[1]).permute(0, 3, 1, 2)]
+            elif same and fuse_cat_eval:
+                # inference: BN (running statistics) + ReLU of every branch in one pass each, written straight into its
+                # channel slice of the concatenated map (no torch.cat copy)
+                widths = [t.shape[1] for t in pre]
+                y = torch.empty((b * h * w, sum(widths)), dtype=torch.float32, device=x.device)
+                off = 0
+                for t, d, wd in zip(pre, self.deblocks, widths):
+                    _bn_eval_rows(t.permute(0, 2, 3, 1).reshape(b * h * w, wd), d[1], True, out=y[:, off:off + wd])
+                    off += wd
                 ups = [y.view(b, h, w, y.shape[1]).permute(0, 3, 1, 2)]
             else:
                 ups = [_run_block(d, t, start=1) for d, t in zip(self.deblocks, pre)]

@@ -69,6 +69,7 @@ SIGNATURES = {
                                    _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "spx_bn_add_relu_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz,
                                    _vp]),
+    "spx_bn_apply": (_int, [_vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _i64, _vp]),
     "spx_anchor_loss_ws_bytes": (_sz, [_int, _i64]),
     "spx_anchor_loss": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _int, _int, ctypes.c_float, ctypes.c_float,
                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _sz,

@@ -602,6 +602,27 @@ def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, 
     return y, mean, invstd
 
 
+def bn_apply(x, mean, invstd, gamma, beta, relu, residual=None, out=None, d_n=None):
+    """Inference-mode BatchNorm (+ residual) (+ReLU) over the rows of x [N, C] with given statistics, one pass.  `out`:
+    optional [N, C] row view with its own stride (a channel slice of a wider matrix)."""
+    _need_gpu(x, mean, invstd, gamma, beta)
+    lib = _lib.load()
+    x = x.contiguous()
+    n, c = x.shape
+    if out is None:
+        y = torch.empty_like(x)
+    else:
+        if not (_row_view_ok(out, n, c) and out.device == x.device):
+            raise ValueError("out must be a float32 [N, C] row view (row stride a multiple of 4, 16-byte aligned)")
+        y = out
+    y_ld = y.stride(0) if n > 1 else c
+    if residual is not None:
+        residual = residual.contiguous()
+    check(lib.spx_bn_apply(_ptr(x), _ptr(residual), n, _ptr(d_n), c, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                           int(bool(relu)), _ptr(y), y_ld, _stream(x)), "spx_bn_apply")
+    return y
+
+
 def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu, residual=None, d_n=None):
     """Backward of bn_relu_fwd; the ReLU mask is recomputed from x (and the residual) inside the kernels (y is not
     read).  dy may be a row view with its own stride (a channel slice of a wider gradient).  Returns dx, dgamma, dbeta
