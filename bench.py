@@ -205,7 +205,7 @@ class KernelTimer(object):
             # reads the table, writes perm and the grouped table
             return t._timed("conv_group", 0.0, 4.0 * (2 * kvol + 1) * n_dst, sv["conv_group"], pair, ld, kvol, n_dst, d_n_dst)
 
-        def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None):
+        def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None, counts=None):
             cout, cin = wshape[0], wshape[-1]
             K = int(np.prod(wshape[1:-1]))
             P = t._P(pair, n_out)
@@ -213,7 +213,7 @@ class KernelTimer(object):
             nbytes = 4.0 * (feat_in.shape[0] * cin + n_out * cout + K * n_out + K * cin * cout)
             # one family per template instantiation (k_wgrad_mfma<cin/16, cout/16, ..>), like the forward kernels
             return t._timed("conv_wgrad[mfma %dx%d]" % (cin, cout), flops, nbytes, sv["conv_wgrad"], feat_in, dout, pair, ld,
-                            n_out, wshape, d_n_out)
+                            n_out, wshape, d_n_out, counts)
 
         def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None):
             n = indices.shape[0]
@@ -232,6 +232,7 @@ class KernelTimer(object):
             return rb
 
         def voxelize(points, *a, **k):
+            t._pairs.clear()      # a new step: the allocator may hand a freed table's address to another table of the same size
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = sv["voxelize"](points, *a, **k)
@@ -363,7 +364,31 @@ def cpu_baseline(cfg_id, mode):
             step(b)
         dt = time.time() - t0
     frames = nb * bs
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+    # BASELINE.json configs[0] (the reference's own CPU-runnable case): KITTI crop, ~16k points / 5k active voxels, batch 1,
+    # voxelise + MeanVFE + VoxelBackBone8x + densify forward on the host (BASELINE.md section 5 protocol, bounded: 3 + 12)
+    crop = None
+    try:
+        _c1, ds1, m1, _o1, _s1 = build(1, dev, "f32")
+        m1.eval()
+        b1 = make_batches(ds1, 1, 1, 0, dev, n=1)[0]
+        ts = []
+        with use_oracle_backend(), torch.no_grad():
+            for i in range(15):
+                bd = {"points": b1["points"], "batch_size": 1}
+                t1 = time.time()
+                for m in m1.module_list[:3]:
+                    bd = m(bd)
+                if i >= 3:
+                    ts.append(time.time() - t1)
+        ts = np.sort(np.asarray(ts))
+        crop = {"workload": "BASELINE configs[0]: KITTI crop, %d pts / %d voxels, batch 1, voxelise + VoxelBackBone8x + densify "
+                            "forward" % (b1["points"].shape[0], bd["voxel_coords"].shape[0]),
+                "frames_s_median": round(1.0 / float(np.median(ts)), 3), "ms_median": round(float(np.median(ts)) * 1e3, 1),
+                "ms_p10": round(float(ts[int(0.1 * len(ts))]) * 1e3, 1), "ms_p90": round(float(ts[int(0.9 * len(ts)) - 1]) * 1e3, 1),
+                "iters": len(ts), "warmup": 3}
+    except Exception as e:                                     # never take the headline down
+        crop = {"error": "%s: %s" % (type(e).__name__, e)}
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port", "configs0_backbone_forward": crop,
             "sample": "%d frames (%d steps of batch %d) of cfg %d, full detector %s; oracle numpy per-offset gather-GEMM-scatter "
                       "sparse ops + torch-CPU dense tail; %.1f s of CPU work after a 1-frame warm-up"
                       % (frames, nb, bs, cfg_id, "fwd+bwd+step" if mode == "train" else "fwd", dt)}

@@ -196,6 +196,11 @@ int spx_conv_rulebook(const int32_t *idx, int64_t n_in, const int64_t *d_n_in, i
  * ---------------------------------------------------------------------------------------------- */
 int spx_pack_weight(const float *w, int cout, int kvol, int cin, int mode, float *packed, spx_stream_t stream);
 
+/* All weights of a network in one launch: d_desc = device int64[n][6] = {w (device pointer, contiguous [Cout][K][Cin]), packed
+ * (device pointer, 2*K*Cin*Cout floats: forward operand then dgrad operand, as mode 2), Cout, K, Cin, first block}; weight i
+ * owns blocks [first block_i, first block_{i+1}) with ceil(2*K*Cin*Cout / 256) blocks each; total_blocks = their sum. */
+int spx_pack_weight_batched(const int64_t *d_desc, int n, int64_t total_blocks, spx_stream_t stream);
+
 int spx_conv_gemm(const float *src, int c_src, const float *w_packed, int c_dst, int kvol, int flip_k,
                   const int32_t *pair, int64_t pair_ld, int64_t n_dst, const int64_t *d_n_dst,
                   const float *scale, const float *shift, int relu, float *dst, spx_stream_t stream);
@@ -228,9 +233,15 @@ int spx_conv_gemm_balanced(const float *src, int c_src, const float *w_packed, i
                            float *dst, void *ws, size_t ws_bytes, spx_stream_t stream);
 
 size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n_out);
+/* counts (nullable): the table's pair counts from spx_conv_wgrad_counts (device, spx_conv_wgrad_counts_bytes); they depend on
+ * the rule table only, so a table that serves several layers / steps of a replayed graph is counted once.  NULL: counted
+ * inside the call. */
+size_t spx_conv_wgrad_counts_bytes(int kvol, int64_t n_out);
+int spx_conv_wgrad_counts(const int32_t *pair, int64_t pair_ld, int kvol, int64_t n_out, const int64_t *d_n_out,
+                          int32_t *counts, spx_stream_t stream);
 int spx_conv_wgrad(const float *in, int cin, const float *dout, int cout, int kvol, const int32_t *pair,
-                   int64_t pair_ld, int64_t n_out, const int64_t *d_n_out, float *dw, void *ws, size_t ws_bytes,
-                   spx_stream_t stream);
+                   int64_t pair_ld, int64_t n_out, const int64_t *d_n_out, const int32_t *counts, float *dw, void *ws,
+                   size_t ws_bytes, spx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 5. Densify (BEV collapse feed)

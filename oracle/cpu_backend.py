@@ -100,7 +100,7 @@ def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=N
     return torch.from_numpy(out.astype(np.float32))
 
 
-def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None):
+def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None, counts=None):
     x, g = _np(feat_in).astype(np.float32), _np(dout).astype(np.float32)
     p = _np(pair)[:, :n_out]
     cout, cin = wshape[0], wshape[-1]

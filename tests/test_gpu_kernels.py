@@ -930,3 +930,29 @@ def test_level_build_odd_strides_and_kernels(orc):
     e = torch.zeros((0, 4), dtype=torch.int32, device=dev)
     rb = ops.conv_rulebook(e, 1, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), subm_ksize=(3, 3, 3))
     assert rb.n_out == 0 and rb.subm_next.n_out == 0
+
+
+def test_pack_all_matches_per_weight_pack():
+    """spx_pack_weight_batched (every conv weight of a backbone, both operand orders, one launch) lays down exactly what
+    spx_pack_weight mode 2 does per weight — MFMA order for 16/32/64/128-channel pairs, plain order for the 4-channel
+    input conv — and refreshes the per-parameter caches only when a weight changed."""
+    from pcdet_amd.config import AttrDict
+    from pcdet_amd.models.backbones_3d import VoxelBackBone8x
+    import spx
+    from spx import functional as F_, ops
+    dev = _dev()
+    torch.manual_seed(2)
+    net = VoxelBackBone8x(AttrDict(), 4, [32, 32, 8]).to(dev)
+    convs = [m for m in net.modules() if isinstance(m, spx.SparseConvolution)]
+    assert len(convs) == 12
+    assert F_.pack_all(convs) is True
+    for m in convs:
+        both = ops.pack_weight(m.weight, 2)
+        half = both.numel() // 2
+        assert torch.equal(F_._packed(m.weight, 0), both[:half]) and torch.equal(F_._packed(m.weight, 1), both[half:])
+    assert F_.pack_all(convs) is False                       # nothing changed: no launch
+    with torch.no_grad():
+        convs[3].weight.mul_(1.5)                            # an in-place update (optimizer step) invalidates
+    assert F_.pack_all(convs) is True
+    both = ops.pack_weight(convs[3].weight, 2)
+    assert torch.equal(F_._packed(convs[3].weight, 0), both[:both.numel() // 2])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev tool: PMC counters for the conv kernels on one layer.
-# usage (GPU box): [KERNEL=k_wgrad_mfma WHAT=wgrad LAYER=conv3.1.0] tools/pmc_conv.sh <tag> [ENV=..]...
+# usage (GPU box): [KERNEL=k_wgrad_mfma WHAT=wgrad LAYER=conv3.1.0 KBARGS="--balanced --group -2"] tools/pmc_conv.sh <tag> [ENV=..]...
 tag=$1; shift
 KERNEL=${KERNEL:-k_conv_mfma}; WHAT=${WHAT:-fwd}; LAYER=${LAYER:-conv3.1.0}
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_LDS" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
-  env "$@" timeout -k 5 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$name -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --what $WHAT --layers $LAYER --iters 3 > $out/$name.log 2>&1
+  env "$@" timeout -k 5 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$name -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --what $WHAT --layers $LAYER --iters 3 $KBARGS > $out/$name.log 2>&1
   echo "pass $name done"
 done
 python3 - <<PY

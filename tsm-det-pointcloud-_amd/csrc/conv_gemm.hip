@@ -66,6 +66,42 @@ __global__ void k_pack_mfma(const float* __restrict__ w, int cout, int K, int ci
   out[t] = w_elem(w, cout, K, cin, mode, k, cs, cd);
 }
 
+// Every convolution weight of a network in ONE launch (both operand orders each): desc[i] = {w, packed, cout, K, cin,
+// first block} as six int64; block b belongs to the last i with first block <= b.  The weights change once per optimizer
+// step, all of them, so one launch replaces 2 x (number of layers) k_pack_mfma launches per step.
+__global__ __launch_bounds__(256) void k_pack_batched(const int64_t* __restrict__ desc, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[6 * mid + 5] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* d = desc + 6 * lo;
+  const float* w = reinterpret_cast<const float*>(d[0]);
+  float* out = reinterpret_cast<float*>(d[1]);
+  const int cout = (int)d[2], K = (int)d[3], cin = (int)d[4];
+  const int total = K * cin * cout;
+  int t = (int)(blockIdx.x - d[5]) * 256 + threadIdx.x;
+  if (t >= 2 * total) return;
+  const int mode = t >= total ? 1 : 0;
+  out += mode * total;
+  t -= mode * total;
+  const int CS = mode == 0 ? cin : cout, CD = mode == 0 ? cout : cin;
+  if (mfma_ok(CS) && mfma_ok(CD)) {
+    const int e = t & 3, lane = (t >> 2) & 63;
+    int rest = t >> 8;
+    const int JG = CS / 16, NT = CD / 16;
+    const int jg = rest % JG;
+    rest /= JG;
+    const int nt = rest % NT;
+    const int k = rest / NT;
+    const int q = lane >> 4, c = lane & 15;
+    out[t] = w_elem(w, cout, K, cin, mode, k, 16 * jg + 4 * q + e, 16 * nt + c);
+  } else {
+    const int cd = t % CD, cs = (t / CD) % CS, k = t / (CD * CS);
+    out[t] = w_elem(w, cout, K, cin, mode, k, cs, cd);
+  }
+}
+
 // plain order [k][cs][cd]
 __global__ void k_pack_plain(const float* __restrict__ w, int cout, int K, int cin, int mode, int CS, int CD,
                              float* __restrict__ out) {
@@ -369,6 +405,13 @@ extern "C" int spx_pack_weight(const float* w, int cout, int kvol, int cin, int 
     hipLaunchKernelGGL(k_pack_mfma, dim3(nb), dim3(256), 0, spx_s(stream), w, cout, kvol, cin, mode, CS, CD, packed);
   else
     hipLaunchKernelGGL(k_pack_plain, dim3(nb), dim3(256), 0, spx_s(stream), w, cout, kvol, cin, mode, CS, CD, packed);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}
+
+extern "C" int spx_pack_weight_batched(const int64_t* d_desc, int n, int64_t total_blocks, spx_stream_t stream) {
+  if (!d_desc || n <= 0 || total_blocks <= 0 || total_blocks >= (int64_t(1) << 31)) return SPX_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_pack_batched, dim3((unsigned)total_blocks), dim3(256), 0, spx_s(stream), d_desc, n);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }

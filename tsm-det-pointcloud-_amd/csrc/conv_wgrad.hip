@@ -471,9 +471,28 @@ extern "C" size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n
     launched = true;                                                                                               \
   }
 
+// Pair counts of a rule table (per offset and 64-row group, per offset and row-eighth): what the work split of
+// spx_conv_wgrad is derived from.  They depend on the table only — not on the channel counts — so a caller computes them
+// once per table (two layers share a submanifold table; the index stream builds them ahead) and passes them in.
+extern "C" size_t spx_conv_wgrad_counts_bytes(int kvol, int64_t n_out) {
+  return wgrad_cnt64_bytes(kvol, n_out < 0 ? 0 : n_out) + spx_align(8 * 32 * sizeof(int32_t));
+}
+
+extern "C" int spx_conv_wgrad_counts(const int32_t* pair, int64_t pair_ld, int kvol, int64_t n_out, const int64_t* d_n_out,
+                                     int32_t* counts, spx_stream_t stream) {
+  if (!pair || !counts || kvol <= 0 || kvol > SPX_MAX_KVOL || n_out <= 0 || pair_ld < n_out) return SPX_ERR_INVALID_ARG;
+  if (n_out >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
+  const int G = (int)((n_out + 63) / 64 + 1);
+  int32_t* cnt8 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(counts) + wgrad_cnt64_bytes(kvol, n_out));
+  hipLaunchKernelGGL(k_wgrad_count, dim3(8, kvol), dim3(1024), 0, spx_s(stream), pair, pair_ld, n_out, d_n_out, kvol, G,
+                     counts, cnt8);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}
+
 extern "C" int spx_conv_wgrad(const float* in, int cin, const float* dout, int cout, int kvol, const int32_t* pair,
-                              int64_t pair_ld, int64_t n_out, const int64_t* d_n_out, float* dw, void* ws,
-                              size_t ws_bytes, spx_stream_t stream) {
+                              int64_t pair_ld, int64_t n_out, const int64_t* d_n_out, const int32_t* counts, float* dw,
+                              void* ws, size_t ws_bytes, spx_stream_t stream) {
   if (!in || !dout || !pair || !dw || cin <= 0 || cout <= 0 || kvol <= 0 || kvol > SPX_MAX_KVOL || n_out < 0 ||
       pair_ld < n_out)
     return SPX_ERR_INVALID_ARG;
@@ -487,9 +506,16 @@ extern "C" int spx_conv_wgrad(const float* in, int cin, const float* dout, int c
   }
   const int J = wgrad_blocks_per_xcd(n_out, cin, cout, kvol);
   const int G = (int)((n_out + 63) / 64 + 1);
-  int32_t* cnt64 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + wgrad_slab_bytes(cin, cout, kvol, n_out));
-  int32_t* cnt8 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(cnt64) + wgrad_cnt64_bytes(kvol, n_out));
-  hipLaunchKernelGGL(k_wgrad_count, dim3(8, kvol), dim3(1024), 0, s, pair, pair_ld, n_out, d_n_out, kvol, G, cnt64, cnt8);
+  const int32_t* cnt64 = counts;
+  const int32_t* cnt8 = counts ? reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(counts) + wgrad_cnt64_bytes(kvol, n_out))
+                               : nullptr;
+  if (!counts) {      // not supplied: count into the workspace
+    int32_t* c64 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + wgrad_slab_bytes(cin, cout, kvol, n_out));
+    int32_t* c8 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(c64) + wgrad_cnt64_bytes(kvol, n_out));
+    hipLaunchKernelGGL(k_wgrad_count, dim3(8, kvol), dim3(1024), 0, s, pair, pair_ld, n_out, d_n_out, kvol, G, c64, c8);
+    cnt64 = c64;
+    cnt8 = c8;
+  }
   float* slab = reinterpret_cast<float*>(ws);
   int MI = (cin + 15) / 16, NJ = (cout + 15) / 16;
   if (MI == 3) MI = 4;

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 import spx as spconv
-from spx.functional import bn_act
+from spx.functional import bn_act, pack_all
 from spx.prebuild import prebuild
 
 from ...utils.spconv_utils import replace_feature  # noqa: F401  (API parity)
@@ -101,8 +101,11 @@ class _TablesAhead(object):
 def _queue_tables(self, x):
     """Static-capacity tensors: every rule table of the stack (+ grouping and work plans) goes to the index stream now and
     is built in the shadow of the convolutions (spx/prebuild.py); exact-size tensors build theirs lazily, as before."""
+    convs = [m for m in self.modules() if isinstance(m, spconv.SparseConvolution)]
+    if x.features.is_cuda and torch.is_grad_enabled():
+        pack_all(convs)              # all packed weight copies of the step in one launch (they all changed in optimizer.step)
     if x.n_valid is not None:
-        prebuild(x, [m for m in self.modules() if isinstance(m, spconv.SparseConvolution)])
+        prebuild(x, convs)
 
 
 def _run_8x_stack(self, batch_dict, with_points_keys):

@@ -45,6 +45,7 @@ SIGNATURES = {
     "spx_conv_rulebook": (_int, [_vp, _i64, _vp, _int, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _vp, _vp, _vp, _vp,
                                  _vp, _i64, _i32p, _i32p, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spx_pack_weight": (_int, [_vp, _int, _int, _int, _int, _vp, _vp]),
+    "spx_pack_weight_batched": (_int, [_vp, _int, _i64, _vp]),
     "spx_conv_gemm": (_int, [_vp, _int, _vp, _int, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp]),
     "spx_conv_plan_bytes": (_sz, [_i64]),
     "spx_conv_plan": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp]),
@@ -54,7 +55,9 @@ SIGNATURES = {
     "spx_conv_gemm_balanced": (_int, [_vp, _int, _vp, _int, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp,
                                       _vp, _sz, _vp]),
     "spx_conv_wgrad_ws_bytes": (_sz, [_int, _int, _int, _i64]),
-    "spx_conv_wgrad": (_int, [_vp, _int, _vp, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "spx_conv_wgrad_counts_bytes": (_sz, [_int, _i64]),
+    "spx_conv_wgrad_counts": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp]),
+    "spx_conv_wgrad": (_int, [_vp, _int, _vp, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spx_densify": (_int, [_vp, _vp, _i64, _vp, _int, _int, _i32p, _int, _vp, _vp]),
     "spx_densify_bwd": (_int, [_vp, _vp, _i64, _vp, _int, _int, _i32p, _int, _vp, _vp]),
     "spx_boxes_iou_bev": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp]),

@@ -44,6 +44,40 @@ def _packed(weight, mode):
     return wp
 
 
+_BANKS = {}
+
+
+def pack_all(convs):
+    """Both operand orders of every weight of `convs` (SparseConvolution modules) in ONE launch, stored where _packed()
+    looks (the per-parameter cache) — the optimizer changes all weights at once, so per step this replaces 2 launches per
+    layer.  No-op while every cached copy is current, on the CPU, and under hipGraph capture."""
+    ws = [m.weight for m in convs if m.weight.is_cuda and m.weight.is_contiguous() and m.weight.dtype == torch.float32]
+    if not ws or torch.cuda.is_current_stream_capturing():
+        return False
+    stale = False
+    for w in ws:
+        c = getattr(w, "_spx_packed", None)
+        geom = (w.data_ptr(), tuple(w.shape), tuple(w.stride()))
+        hit = None if c is None else c.get((0,) + geom)
+        if hit is None or hit[0] != w._version:
+            stale = True
+            break
+    if not stale:
+        return False
+    key = id(convs[0])
+    bank = _BANKS.get(key)
+    if bank is None or not bank.valid_for(ws):
+        bank = _BANKS[key] = ops.PackedBank(ws)
+    bank.repack()
+    for w, (fwd, bwd) in zip(ws, bank.views):
+        geom = (w.data_ptr(), tuple(w.shape), tuple(w.stride()))
+        try:
+            w._spx_packed = {(0,) + geom: (w._version, fwd), (1,) + geom: (w._version, bwd)}
+        except AttributeError:
+            pass
+    return True
+
+
 def _conv(src, wp, c_dst, kvol, pair, ld, n_dst, flip, scale, shift, relu, d_n, rb):
     """One gather-GEMM launch: the MFMA-work-balanced persistent schedule where it applies (plan cached on the rulebook;
     over rows grouped by offset mask for submanifold tables, which several launches share), the one-tile-per-wave
@@ -105,7 +139,10 @@ def _conv_backward(feats, weight, tables, rb, d_n_src, has_bias, dout, needs, d_
         wt = _packed(weight, 1)
         dfe = _conv(dout, wt, cin, kvol, pair_b, ld_b, feats.shape[0], flip_b, None, None, False, d_n_src, rb)
     if needs[1]:
-        dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape), d_n_out=d_n_dst)
+        counts = None
+        if rb is not None and feats.is_cuda and n_dst > 0 and feats.shape[0] > 0:
+            counts = ops.wgrad_counts_for(rb, pair_f, ld_f, kvol, n_dst, d_n_dst)
+        dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape), d_n_out=d_n_dst, counts=counts)
     if has_bias and needs[2]:
         if d_n_dst is not None:
             raise RuntimeError("bias gradient of a static-capacity tensor is not implemented (rows beyond the live count "

@@ -320,6 +320,35 @@ def pack_weight(weight, mode):
     return packed                # mode 2: forward operand in the first half, dgrad operand in the second
 
 
+class PackedBank(object):
+    """Both MFMA operand orders of a fixed list of contiguous weights, re-packed by ONE launch (spx_pack_weight_batched).
+    halves(i) -> (forward operand, dgrad operand) views of weight i."""
+
+    def __init__(self, weights):
+        self.weights = list(weights)
+        dev = self.weights[0].device
+        sizes = [w.numel() for w in self.weights]
+        self.flat = torch.empty((2 * sum(sizes),), dtype=torch.float32, device=dev)
+        rows, off, blk = [], 0, 0
+        self.views = []
+        for w, n in zip(self.weights, sizes):
+            cout, cin = w.shape[0], w.shape[-1]
+            rows.append([w.data_ptr(), self.flat.data_ptr() + 4 * off, cout, n // (cout * cin), cin, blk])
+            self.views.append((self.flat[off:off + n], self.flat[off + n:off + 2 * n]))
+            off += 2 * n
+            blk += (2 * n + 255) // 256
+        self.blocks = blk
+        self.desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.ptrs = tuple(w.data_ptr() for w in self.weights)
+
+    def valid_for(self, weights):
+        return len(weights) == len(self.weights) and tuple(w.data_ptr() for w in weights) == self.ptrs
+
+    def repack(self):
+        check(_lib.load().spx_pack_weight_batched(_ptr(self.desc), len(self.weights), self.blocks, _stream(self.flat)),
+              "spx_pack_weight_batched")
+
+
 def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False,
               d_n_dst=None):
     """d_n_dst: optional device int64[1] live destination-row count (n_dst is then the launch capacity; rows beyond the
@@ -423,8 +452,28 @@ def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k
     return dst
 
 
-def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None):
-    """d_n_out: optional device int64[1] live output-row count (n_out is then the capacity)."""
+def wgrad_counts(pair, ld, kvol, n_out, d_n_out=None):
+    """Pair counts of a rule table for conv_wgrad's work split (include/spx.h: spx_conv_wgrad_counts); int32 device tensor."""
+    _need_gpu(pair)
+    lib = _lib.load()
+    counts = torch.empty((lib.spx_conv_wgrad_counts_bytes(kvol, n_out) // 4,), dtype=torch.int32, device=pair.device)
+    check(lib.spx_conv_wgrad_counts(_ptr(pair), ld, kvol, n_out, _ptr(d_n_out), _ptr(counts), _stream(pair)),
+          "spx_conv_wgrad_counts")
+    return counts
+
+
+def wgrad_counts_for(rb, pair, ld, kvol, n_out, d_n_out=None):
+    """Counts of rule table `pair`, computed once per Rulebook (shared by the layers that use the table)."""
+    key = ("wc", pair.data_ptr(), int(n_out))
+    hit = rb._plans.get(key)
+    if hit is None:
+        hit = rb._plans[key] = wgrad_counts(pair, ld, kvol, n_out, d_n_out)
+    return hit
+
+
+def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None, counts=None):
+    """d_n_out: optional device int64[1] live output-row count (n_out is then the capacity); counts: wgrad_counts of the
+    table (computed inside the call when None)."""
     _need_gpu(feat_in, dout, pair)
     lib = _lib.load()
     feat_in = feat_in.contiguous()
@@ -438,7 +487,8 @@ def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None):
         return dw.zero_()
     wsb = lib.spx_conv_wgrad_ws_bytes(cin, cout, K, n_out)
     ws = workspace(dout.device, wsb)
-    check(lib.spx_conv_wgrad(_ptr(feat_in), cin, _ptr(dout), cout, K, _ptr(pair), ld, n_out, _ptr(d_n_out), _ptr(dw), _ptr(ws),
+    check(lib.spx_conv_wgrad(_ptr(feat_in), cin, _ptr(dout), cout, K, _ptr(pair), ld, n_out, _ptr(d_n_out), _ptr(counts),
+                             _ptr(dw), _ptr(ws),
                              wsb, _stream(dout)), "spx_conv_wgrad")
     return dw
 

@@ -35,6 +35,8 @@ def _plans(rb, conv, backward):
             jobs.append((cout, cin, rb.pair, rb.ld, rb.n_in, rb.d_n_in))
         else:
             jobs.append((cout, cin, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in, rb.d_n_in))
+    if backward and rb.n_out > 0 and rb.n_in > 0:
+        ops.wgrad_counts_for(rb, rb.pair, rb.ld, kvol, rb.n_out, rb.d_n_out)      # the weight gradient's work split
     for c_src, c_dst, pair, ld, n_dst, d_n in jobs:
         if n_dst <= 0 or not ops.balanced_ok(c_src, c_dst, n_dst, rb, pair):
             continue
