@@ -41,8 +41,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SPX_CB_WPB
 #define SPX_CB_WPB 4
 #endif
-constexpr int kWpb = SPX_CB_WPB;     // waves per workgroup = 16-row tiles per super-tile (4: 64 rows, 16: 256 rows)
-constexpr int kRows = 16 * kWpb;    // destination rows per super-tile
+#ifndef SPX_CB_TPW
+#define SPX_CB_TPW 1
+#endif
+constexpr int kWpb = SPX_CB_WPB;     // waves per workgroup
+constexpr int kTpw = SPX_CB_TPW;     // 16-row tiles per wave (dev builds: 2 = twice the MFMA work between two barriers)
+constexpr int kTps = kWpb * kTpw;    // 16-row tiles per super-tile
+constexpr int kRows = 16 * kTps;     // destination rows per super-tile
 constexpr int kBlocks = 4096 / kWpb;   // persistent workgroups: 4 waves per SIMD in total (256 CUs x 4 SIMDs)
 constexpr int kLdsPerBlock = 36 * 1024;   // LDS footprint forced per workgroup: four fit a CU's 160 KiB, a fifth not
 constexpr int kPreLds = 12 * 1024;  // prefix entries staged in LDS by the plan kernel (786k rows)
@@ -53,7 +58,7 @@ constexpr int kHdr = 4;             // plan header: [0] active workgroups nb, [1
 // arriver, so a plan serves any number of launches — one at a time (forward, dgrad, the sibling layer run in stream order).
 __host__ __device__ inline int64_t plan_off_wstart() { return kHdr; }
 __host__ __device__ inline int64_t plan_off_mask() { return kHdr + (kBlocks + 1 + 3) / 4 * 4; }   // 16-byte aligned
-__host__ __device__ inline int64_t plan_off_pre(int64_t t4cap) { return plan_off_mask() + kWpb * t4cap; }
+__host__ __device__ inline int64_t plan_off_pre(int64_t t4cap) { return plan_off_mask() + kTps * t4cap; }
 __host__ __device__ inline int64_t plan_off_arr(int64_t t4cap) { return plan_off_pre(t4cap) + t4cap + 1; }
 __host__ __device__ inline int64_t plan_ints(int64_t t4cap) { return plan_off_arr(t4cap) + t4cap; }
 
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void k_plan_mask(const int32_t* __restrict__ p
       if ((b >> (16 * sub)) & 0xFFFFull) m |= 1u << (k0 + u);
     }
   }
-  if (r == 0 && tile < kWpb * t4cap) plan[plan_off_mask() + tile] = tile < T ? (int32_t)m : 0;
+  if (r == 0 && tile < kTps * t4cap) plan[plan_off_mask() + tile] = tile < T ? (int32_t)m : 0;
 }
 
 // ---------------------------------------------------------------- plan, pass 2 (one block): prefix over super-tiles, cuts
@@ -102,8 +107,8 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t n, const int64_t* d_
     if (S < T4) {
       int many = 0;
 #pragma unroll
-      for (int i = 0; i < kWpb; i += 4) {
-        const int4 m = *reinterpret_cast<const int4*>(mask + (size_t)kWpb * S + i);
+      for (int i = 0; i < kTps; i += 4) {
+        const int4 m = *reinterpret_cast<const int4*>(mask + (size_t)kTps * S + i);
         many |= m.x | m.y | m.z | m.w;
       }
       v = __popc((unsigned)many);                        // super-units: offsets present in any tile of the super-tile
@@ -190,8 +195,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // workgroup — measured: +25 us per launch), every storing wave drains its stores, the workgroup meets at a barrier, ONE
 // lane draws the tile's ticket with an agent-scope atomic; the workgroup that draws the last ticket acquires once
 // (invalidates its CU's L1) and reads every slab with `sc1` loads.
-__device__ __forceinline__ int slab_byte_off(int slot_index, int tile_floats, int NT, int wave, int nt, int lane) {
-  return (slot_index * (tile_floats / 4) + (wave * NT + nt) * 64 + lane) * 16;
+__device__ __forceinline__ int slab_byte_off(int slot_index, int tile_floats, int NT, int wave, int nt, int lane, int t = 0) {
+  return (slot_index * (tile_floats / 4) + ((wave * kTpw + t) * NT + nt) * 64 + lane) * 16;
 }
 
 // Called by ALL threads of a workgroup right after they stored their partial of shared super-tile S (sc1 stores).
@@ -227,35 +232,37 @@ __device__ __forceinline__ void tile_combine(int S, int owners, const int32_t* _
   constexpr int NT = CD / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
   const int b_lo = (owners - 1) & 0xFFF, b_hi = (owners - 1) >> 12;
-  f32x4 acc[NT];
+  for (int t = 0; t < kTpw; ++t) {
+    f32x4 acc[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int b = b_lo; b <= b_hi; ++b) {
-    const int slot = 2 * b + (wstart[b] == S ? 0 : 1);
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = b_lo; b <= b_hi; ++b) {
+      const int slot = 2 * b + (wstart[b] == S ? 0 : 1);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, slab_byte_off(slot, kRows * CD, NT, wave, nt, lane), 0, 16);
-      acc[nt] += __builtin_bit_cast(f32x4, u);
+      for (int nt = 0; nt < NT; ++nt) {
+        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, slab_byte_off(slot, kRows * CD, NT, wave, nt, lane, t), 0, 16);
+        acc[nt] += __builtin_bit_cast(f32x4, u);
+      }
     }
-  }
-  int64_t drow[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int64_t orow = (int64_t)S * kRows + 16 * wave + 4 * q + e;
-    drow[e] = orow < nlive ? (perm ? (int64_t)perm[orow] : orow) : -1;
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = 16 * nt + r;
-    const float sc = scale ? scale[col] : 1.0f;
-    const float sh = shift ? shift[col] : 0.0f;
+    int64_t drow[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (drow[e] >= 0) {
-        float v = acc[nt][e];
-        if (scale || shift) v = v * sc + sh;
-        if (relu) v = v > 0.f ? v : 0.f;
-        dst[drow[e] * CD + col] = v;
+      const int64_t orow = (int64_t)S * kRows + 16 * (kTpw * wave + t) + 4 * q + e;
+      drow[e] = orow < nlive ? (perm ? (int64_t)perm[orow] : orow) : -1;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = 16 * nt + r;
+      const float sc = scale ? scale[col] : 1.0f;
+      const float sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (drow[e] >= 0) {
+          float v = acc[nt][e];
+          if (scale || shift) v = v * sc + sh;
+          if (relu) v = v > 0.f ? v : 0.f;
+          dst[drow[e] * CD + col] = v;
+        }
       }
     }
   }
@@ -288,7 +295,7 @@ __device__ __forceinline__ void write_empty_tiles(int blk, int nb, int T4, const
 
 // ---------------------------------------------------------------- persistent, balanced, block-lockstep implicit GEMM
 template <int CS, int CD>
-__global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv_mfma_pbl(const float* __restrict__ src, const float* __restrict__ wp,
+__global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(kTpw == 1 ? 4 : 3, kTpw == 1 ? 4 : 4))) void k_conv_mfma_pbl(const float* __restrict__ src, const float* __restrict__ wp,
                                                        const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
                                                        int64_t n, const int64_t* d_n, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu,
@@ -329,27 +336,34 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
   // ---- the workgroup's super-units in order (all values wave-uniform and equal in the four waves)
   struct Cur {
     int S, k;            // super-tile, loop index of the offset (weights W_k, table row trow(k)); S < 0: past the end
-    uint32_t mself;      // offset mask of THIS wave's tile of S
+    uint32_t mself[kTpw];   // offset masks of THIS wave's tiles of S
     int whole;           // S belongs to this workgroup alone
   };
   int it_S = s_first - 1;
-  uint32_t it_todo = 0, it_mself = 0;
+  uint32_t it_todo = 0, it_mself[kTpw];
+#pragma unroll
+  for (int t = 0; t < kTpw; ++t) it_mself[t] = 0;
   int it_whole = 0;
   auto next = [&]() -> Cur {
+    Cur out;
+    out.S = -1, out.k = 0, out.whole = 0;
+#pragma unroll
+    for (int t = 0; t < kTpw; ++t) out.mself[t] = 0u;
     while (it_todo == 0) {
       ++it_S;
-      if (it_S >= T4) return Cur{-1, 0, 0u, 0};
+      if (it_S >= T4) return out;
       const int p0 = pre[it_S];
-      if (p0 >= u1) return Cur{-1, 0, 0u, 0};
+      if (p0 >= u1) return out;
       const int work = pre[it_S + 1] - p0;
-      if (work == 0) continue;                                   // empty super-tile: written by the fix-up kernel
+      if (work == 0) continue;                                   // empty super-tile: written up front (write_empty_tiles)
       uint32_t many = 0;
 #pragma unroll
-      for (int i = 0; i < kWpb; i += 4) {
-        const int4 m4 = *reinterpret_cast<const int4*>(mask + (size_t)kWpb * it_S + i);
+      for (int i = 0; i < kTps; i += 4) {
+        const int4 m4 = *reinterpret_cast<const int4*>(mask + (size_t)kTps * it_S + i);
         many |= (uint32_t)(m4.x | m4.y | m4.z | m4.w);
       }
-      it_mself = (uint32_t)mask[(size_t)kWpb * it_S + wave];
+#pragma unroll
+      for (int t = 0; t < kTpw; ++t) it_mself[t] = (uint32_t)mask[(size_t)kTps * it_S + kTpw * wave + t];
       it_whole = (u0 <= p0 && p0 + work <= u1) ? 1 : 0;
       int c = p0;
       for (int k = 0; k < K; ++k) {                              // owned: super-units whose index lies in [u0, u1)
@@ -359,9 +373,13 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
         ++c;
       }
     }
-    const int k = __ffs((int)it_todo) - 1;
+    out.S = it_S;
+    out.k = __ffs((int)it_todo) - 1;
     it_todo &= it_todo - 1;
-    return Cur{it_S, k, it_mself, it_whole};
+#pragma unroll
+    for (int t = 0; t < kTpw; ++t) out.mself[t] = it_mself[t];
+    out.whole = it_whole;
+    return out;
   };
 
   auto copy_w = [&](int k, int buf) {
@@ -376,9 +394,9 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
   };
   // (Returning the entry raw and applying its validity at the consumers removes the wait the compiler puts right behind
   // this load, but the kernel then runs 5 % SLOWER — measured, same call — so the select stays here.)
-  auto load_id = [&](const Cur& c) -> int32_t {              // unconditional (row clamped); -1 where not applicable
+  auto load_id = [&](const Cur& c, int t) -> int32_t {       // unconditional (row clamped); -1 where not applicable
     const int S = c.S >= 0 ? c.S : 0;
-    const int64_t row = (int64_t)S * kRows + 16 * wave + r;
+    const int64_t row = (int64_t)S * kRows + 16 * (kTpw * wave + t) + r;
     const int64_t rc = row < nlive ? row : nlive - 1;
     const int32_t v = pair[(int64_t)(flip ? K - 1 - c.k : c.k) * ld + rc];
     return (c.S >= 0 && row < nlive) ? v : -1;
@@ -389,9 +407,11 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
     for (int jg = 0; jg < JG; ++jg) a[jg] = *reinterpret_cast<const f32x4*>(p + 16 * jg);
   };
 
-  f32x4 acc[NT];
+  f32x4 acc[kTpw][NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < kTpw; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Pipeline: while super-unit c0 is multiplied, the rows of c1 and the weight slice of c1 are in flight and the rule
   // entries of c2 are read; the barrier at the top of each trip is the one point where they are waited for.
@@ -400,10 +420,13 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
   unsigned long long d_bar = 0, d_mma = 0, d_units = 0, d_act = 0;
 #endif
   Cur c0 = next(), c1 = next(), c2 = next();
-  int32_t id0 = load_id(c0), id1 = load_id(c1);
+  int32_t id0[kTpw], id1[kTpw];
+  f32x4 a_cur[kTpw][JG], a_nxt[kTpw][JG];
+#pragma unroll
+  for (int t = 0; t < kTpw; ++t) id0[t] = load_id(c0, t), id1[t] = load_id(c1, t);
   if (c0.S >= 0) copy_w(c0.k, 0);
-  f32x4 a_cur[JG], a_nxt[JG];
-  gather(id0, a_cur);
+#pragma unroll
+  for (int t = 0; t < kTpw; ++t) gather(id0[t], a_cur[t]);
   int it = 0;
   while (c0.S >= 0) {
 #ifdef SPX_CV_DIAG
@@ -414,19 +437,29 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
     d_bar += __builtin_amdgcn_s_memtime() - d_a;
     d_units += 1;
 #endif
-    const int32_t id2 = load_id(c2);
-    gather(id1, a_nxt);
+    int32_t id2[kTpw];
+#pragma unroll
+    for (int t = 0; t < kTpw; ++t) id2[t] = load_id(c2, t);
+#pragma unroll
+    for (int t = 0; t < kTpw; ++t) gather(id1[t], a_nxt[t]);
     if (c1.S >= 0) copy_w(c1.k, (it + 1) & 1);
     // everything above is only ISSUED here; keep it above the MFMAs (the scheduler would otherwise sink the gathers
     // next to their use in the next trip and serialise latency and arithmetic again)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     const int tr0 = flip ? K - 1 - c0.k : c0.k;
+    bool act[kTpw];
+    bool any_act = false;
+#pragma unroll
+    for (int t = 0; t < kTpw; ++t) {
+      act[t] = (c0.mself[t] >> tr0) & 1u;   // wave-uniform: this tile has the offset
+      any_act |= act[t];
+    }
 #ifdef SPX_CV_DIAG
     const unsigned long long d_c = __builtin_amdgcn_s_memtime();
-    if ((c0.mself >> tr0) & 1u) d_act += 1;
+    if (any_act) d_act += 1;
 #endif
-    if ((c0.mself >> tr0) & 1u) {            // wave-uniform: this wave's tile has the offset
+    if (any_act) {
       const f32x4* B = sB[it & 1];
 #pragma unroll
       for (int jg = 0; jg < JG; ++jg) {
@@ -434,10 +467,15 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b[nt] = B[(nt * JG + jg) * 64 + lane];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float av = id0 >= 0 ? a_cur[jg][e] : 0.f;
+        for (int t = 0; t < kTpw; ++t) {
+          if (!act[t]) continue;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt][e], acc[nt], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            const float av = id0[t] >= 0 ? a_cur[t][jg][e] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt][e], acc[t][nt], 0, 0, 0);
+          }
         }
       }
     }
@@ -445,27 +483,30 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
     d_mma += __builtin_amdgcn_s_memtime() - d_c;
 #endif
     if (c1.S != c0.S) {
-      // last owned offset of super-tile c0.S: write this wave's 16 rows.  C layout: col = lane&15, row = 4*(lane>>4) + e
-      const int64_t row_base = (int64_t)c0.S * kRows + 16 * wave;
+      // last owned offset of super-tile c0.S: write this wave's rows.  C layout: col = lane&15, row = 4*(lane>>4) + e
       if (c0.whole) {
-        int64_t drow[4];                       // where the rows of this position go: perm[] under a grouped row order
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int64_t orow = row_base + 4 * q + e;
-          drow[e] = orow < nlive ? (perm ? (int64_t)perm[orow] : orow) : -1;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int col = 16 * nt + r;
-          const float sc = scale ? scale[col] : 1.0f;
-          const float sh = shift ? shift[col] : 0.0f;
+        for (int t = 0; t < kTpw; ++t) {
+          const int64_t row_base = (int64_t)c0.S * kRows + 16 * (kTpw * wave + t);
+          int64_t drow[4];                     // where the rows of this position go: perm[] under a grouped row order
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (drow[e] >= 0) {
-              float v = acc[nt][e];
-              if (scale || shift) v = v * sc + sh;
-              if (relu) v = v > 0.f ? v : 0.f;
-              dst[drow[e] * CD + col] = v;
+            const int64_t orow = row_base + 4 * q + e;
+            drow[e] = orow < nlive ? (perm ? (int64_t)perm[orow] : orow) : -1;
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int col = 16 * nt + r;
+            const float sc = scale ? scale[col] : 1.0f;
+            const float sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (drow[e] >= 0) {
+                float v = acc[t][nt][e];
+                if (scale || shift) v = v * sc + sh;
+                if (relu) v = v > 0.f ? v : 0.f;
+                dst[drow[e] * CD + col] = v;
+              }
             }
           }
         }
@@ -474,20 +515,27 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(4, 4)
         // super-tile, else slot 1
         const int slot = 2 * blk + (c0.S == s_first ? 0 : 1);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nt]), rs_scratch,
-                                                 slab_byte_off(slot, kRows * CD, NT, wave, nt, lane), 0, 16);
+        for (int t = 0; t < kTpw; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][nt]), rs_scratch,
+                                                   slab_byte_off(slot, kRows * CD, NT, wave, nt, lane, t), 0, 16);
         const int p0 = pre[c0.S];
         const int owners = tile_arrive(c0.S, p0, pre[c0.S + 1] - p0, U, nb, arrivals, s_flag);
         if (owners) tile_combine<CD>(c0.S, owners, plan + plan_off_wstart(), rs_scratch, nlive, scale, shift, relu, perm, dst);
       }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < kTpw; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int jg = 0; jg < JG; ++jg) a_cur[jg] = a_nxt[jg];
-    id0 = id1;
-    id1 = id2;
+    for (int t = 0; t < kTpw; ++t) {
+#pragma unroll
+      for (int jg = 0; jg < JG; ++jg) a_cur[t][jg] = a_nxt[t][jg];
+      id0[t] = id1[t];
+      id1[t] = id2[t];
+    }
     c0 = c1;
     c1 = c2;
     c2 = next();
@@ -527,6 +575,7 @@ __global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(2, 2)
     const int32_t* __restrict__ plan, int64_t t4cap, const int32_t* __restrict__ perm, float* __restrict__ dst,
     float* __restrict__ scratch, int32_t* arrivals) {
   static_assert(kWpb == 4, "two-half kernel is written for 4 waves per workgroup");
+  if constexpr (kTpw != 1) return;          // dev builds with two tiles per wave do not cover the 128-channel kernel
   constexpr int NT = CD / 16;
   constexpr int NTH = NT / 2;               // column tiles per half
   constexpr int JG = CS / 16;
@@ -733,7 +782,7 @@ extern "C" int spx_conv_plan(const int32_t* pair, int64_t pair_ld, int kvol, int
   if (n_dst >= (int64_t(1) << 31)) return SPX_ERR_TOO_LARGE;
   hipStream_t s = spx_s(stream);
   const int64_t t4cap = tiles4_cap(n_dst);
-  hipLaunchKernelGGL(k_plan_mask, dim3((unsigned)((kWpb * t4cap + 15) / 16)), dim3(256), 0, s, pair, pair_ld, kvol, n_dst,
+  hipLaunchKernelGGL(k_plan_mask, dim3((unsigned)((kTps * t4cap + 15) / 16)), dim3(256), 0, s, pair, pair_ld, kvol, n_dst,
                      d_n_dst, t4cap, plan);
   hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, s, n_dst, d_n_dst, t4cap, plan);
   SPX_CHECK_LAUNCH();
@@ -768,7 +817,7 @@ extern "C" int spx_conv_gemm_balanced(const float* src, int c_src, const float* 
   SPX_PB_CASE(32, 64)
   SPX_PB_CASE(64, 32)
   SPX_PB_CASE(64, 64)
-  if (c_src == 128 && c_dst == 128 && kWpb == 4) {
+  if (c_src == 128 && c_dst == 128 && kWpb == 4 && kTpw == 1) {
     launch_pb2<128, 128>(src, w_packed, pair, pair_ld, kvol, flip_k, n_dst, d_n_dst, scale, shift, relu, plan, perm, dst, scratch,
                          s);
     SPX_CHECK_LAUNCH();
