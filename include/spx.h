@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SPX_ABI_VERSION 1
+#define SPX_ABI_VERSION 2
 
 #define SPX_OK 0
 #define SPX_ERR_INVALID_ARG (-1)  /* null pointer, non-positive extent, kernel volume > SPX_MAX_KVOL ... */

@@ -62,6 +62,9 @@ static inline int wgrad_splits(int64_t n, int cin, int cout, int kvol) {
 // Blocks of one XCD dealt to the K offsets: S_k = 1 + (J-K) * cnt[k] / sum(cnt)  (J >= K), evaluated on counts
 // pre-shifted so that the product fits 32 bits (sum of floors <= floor of sum keeps the total within J).  Called by a
 // full wave; lane k < K returns its S_k, the exclusive prefix start_k and its count.
+// (Round 2 tried the min-max split instead — S_k = max(1, ceil(cnt[k] / T)), T the smallest pairs-per-block that fits J
+// blocks, by bisection: every layer got 9-27 us SLOWER (profiles/r02_conv_experiments.md); so did deeper bursts and more,
+// smaller blocks.  The proportional split stays.)
 __device__ __forceinline__ void wgrad_plan(const int32_t* __restrict__ cnt, int K, int J, int lane, int& sk, int& start,
                                            int& mycnt) {
   const uint32_t cval = lane < K ? (uint32_t)cnt[lane] : 0u;

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL — see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPX_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libspx.so")   # SPX_LIB_PATH: dev override (A/B of two builds)
 
-SPX_ABI_VERSION = 1
+SPX_ABI_VERSION = 2
 SPX_MAX_KVOL = 32
 
 _vp = ctypes.c_void_p
