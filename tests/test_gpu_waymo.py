@@ -339,3 +339,35 @@ def test_cfg5_waymo_detector_forward_finite():
         assert bool(torch.isfinite(v.features).all()), k
     assert bd["batch_box_preds"].shape[0] == 1 and bool(torch.isfinite(bd["batch_box_preds"]).all())
     assert bool(torch.isfinite(bd["batch_cls_preds"]).all())
+
+
+def test_million_row_dispatch_branches(orc):
+    """Row counts beyond anything the synthetic configs produce: >= 2^20 destination rows switches spx_conv_gemm to four
+    16-row tiles per wave (MT = 4), and a plan over more than 786k rows leaves the LDS-resident prefix of k_plan_scan.
+    Synthetic rule table (random neighbours, 10 % density), 16->16 through spx_conv_gemm and 64->64 through the balanced
+    schedule, against the numpy oracle; bitwise identical on a second launch."""
+    from spx import ops
+    dev = _dev()
+    n, K = 1_100_000, 27
+    rs = np.random.RandomState(9)
+    pair_np = np.where(rs.rand(K, n) < 0.10, rs.randint(0, n, size=(K, n)), -1).astype(np.int32)
+    pair_np[13] = np.arange(n, dtype=np.int32)                    # the centre offset of a submanifold table
+    pair = torch.from_numpy(pair_np).to(dev)
+    g = torch.Generator().manual_seed(4)
+    for cs, cd, balanced in ((16, 16, False), (64, 64, True)):
+        x = torch.randn(n, cs, generator=g)
+        w = torch.randn(cd, K, cs, generator=g) / np.sqrt(K * cs * 0.1)
+        wp = ops.pack_weight(w.to(dev), 0)
+        xg = x.to(dev)
+        if balanced:
+            plan = ops.conv_plan(pair, n, K, n)
+            assert int(plan[2]) == (n + 63) // 64 and int(plan[2]) + 1 > 12 * 1024      # beyond the LDS prefix of the plan scan
+            out = ops.conv_gemm_balanced(xg, wp, cd, K, pair, n, n, plan)
+            again = ops.conv_gemm_balanced(xg, wp, cd, K, pair, n, n, plan)
+        else:
+            out = ops.conv_gemm(xg, wp, cd, K, pair, n, n)
+            again = ops.conv_gemm(xg, wp, cd, K, pair, n, n)
+        assert torch.equal(out, again)
+        ref = orc.conv_fwd_gemm(x.numpy(), w.view(cd, 3, 3, 3, cs).numpy(), pair_np)
+        _close(out.cpu().numpy(), ref)
+        del out, again, xg, ref

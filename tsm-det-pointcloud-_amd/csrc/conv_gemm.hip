@@ -366,6 +366,10 @@ template <int CS, int CD>
 static int launch_mfma(const float* src, const float* wp, const int32_t* pair, int64_t ld, int K, int flip, int64_t n,
                        const int64_t* d_n, const float* scale, const float* shift, int relu, float* dst,
                        hipStream_t s) {
+  // (Round 2 tried a kernel that keeps ALL K weight slices of a 16/32-channel layer in LDS — one 16-wave workgroup per CU,
+  // tiles in equal contiguous shares, rows of four offsets gathered together: 58 us against 51 us for k_conv_mfma_sm at
+  // 32->32 / 83 k rows; ablation: 22 us skeleton, +8 us gathers, +28..50 us LDS-read + MFMA phase at four waves per SIMD.
+  // Not kept; profiles/r02_conv_experiments.md.)
   if constexpr (CS * CD <= 2048) {
     if (n < (int64_t(1) << 18)) {        // low-channel layers: the latency form
       int64_t waves1 = (n + 15) / 16;
