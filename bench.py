@@ -310,8 +310,7 @@ def roofline_of(fam):
     rocprof_name, extra_name = "?", None
     if name.startswith("conv_gemm[mfma ") and name.endswith(" balanced]"):
         cs, cd = name[len("conv_gemm[mfma "):-len(" balanced]")].split("x")
-        rocprof_name = "k_conv_mfma_pbl%s<%s, %s>" % ("2" if cs == "128" else "", cs, cd)   # + its k_conv_fixup<cd>
-        extra_name = "k_conv_fixup<%s>" % cd
+        rocprof_name = "k_conv_mfma_pbl%s<%s, %s>" % ("2" if cs == "128" else "", cs, cd)   # one kernel since round 2
     elif name.startswith("conv_gemm[mfma "):
         cs, cd = name[len("conv_gemm[mfma "):-1].split("x")
         rocprof_name = "k_conv_mfma<%s, %s," % (cs, cd)
