@@ -733,3 +733,47 @@ def test_bev_eval_fused_bn_relu_and_cat_match_plain_modules():
     assert fused["spatial_features_2d"].shape == (2, 256, 48, 40)
     assert fused["spatial_features_2d"].is_contiguous(memory_format=torch.channels_last)
     assert float(fused["spatial_features_2d"].min()) >= 0.0
+
+
+def test_res_backbone_static_capacity_matches_dynamic():
+    """VoxelResBackBone8x (SparseBasicBlock: biased convs, bn2 + identity + ReLU) trained at static row capacities with its
+    rule tables on the index stream (the submanifold tables of levels 2-4 come out of the strided builds, keys res2..res4)
+    against the exact-size path: live rows of the encoded tensor and every parameter gradient."""
+    from pcdet_amd.config import AttrDict
+    from pcdet_amd.datasets import SyntheticDataset
+    from pcdet_amd.models.backbones_3d import VoxelResBackBone8x
+    from spx import ops
+    ds = SyntheticDataset(cfg_id=0)
+    torch.manual_seed(4)
+    dev = torch.device("cuda:0")
+    net = VoxelResBackBone8x(AttrDict(), 4, ds.grid_size).to(dev).train()
+    twin = copy.deepcopy(net)
+    pts = _batch(ds)["points"].to(dev)
+    ops.status_word(dev).zero_()
+
+    def run(model, static):
+        vox = ops.voxelize(pts, ds.point_cloud_range, ds.voxel_size, 5, 16000, batch_size=2, batch_col=0, xyz_col=1,
+                           feat_col=1, want_voxels=False, sync=not static)
+        bd = {"voxel_features": vox["mean"], "voxel_coords": vox["coords"], "batch_size": 2}
+        if static:
+            cap = vox["coords"].shape[0]
+            bd["voxel_num_valid"] = vox["d_num_voxels"]
+            bd["static_caps"] = {"spconv2": 6 * cap, "spconv3": 6 * cap, "spconv4": 4 * cap, "spconv_down2": 4 * cap}
+        out = model(bd)["encoded_spconv_tensor"]
+        n = out.features.shape[0] if out.n_valid is None else int(out.n_valid)
+        f = out.features[:n]
+        (f * torch.linspace(-1, 1, f.numel(), device=f.device).view_as(f)).sum().backward()
+        return out, f
+
+    out_d, f_d = run(net, False)
+    out_s, f_s = run(twin, True)
+    ops.check_status(dev)
+    assert f_s.shape == f_d.shape and torch.equal(out_s.indices[:f_d.shape[0]], out_d.indices)
+    assert sorted(k for k in out_s.indice_dict) == sorted(k for k in out_d.indice_dict)
+    assert _rel(f_s, f_d) < 1e-4
+    num = den = 0.0
+    for (n, p), (_, q) in zip(twin.named_parameters(), net.named_parameters()):
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+        num += float((p.grad.double() - q.grad.double()).pow(2).sum())
+        den += float(q.grad.double().pow(2).sum())
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5

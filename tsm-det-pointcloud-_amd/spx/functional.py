@@ -145,9 +145,11 @@ def _conv_backward(feats, weight, tables, rb, d_n_src, has_bias, dout, needs, d_
         dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape), d_n_out=d_n_dst, counts=counts)
     if has_bias and needs[2]:
         if d_n_dst is not None:
-            raise RuntimeError("bias gradient of a static-capacity tensor is not implemented (rows beyond the live count "
-                               "are undefined)")
-        db = dout.sum(0)
+            # rows beyond the live count are undefined (possibly NaN): select, do not multiply
+            live = torch.arange(dout.shape[0], device=dout.device).unsqueeze(1) < d_n_dst
+            db = torch.where(live, dout, torch.zeros((), dtype=dout.dtype, device=dout.device)).sum(0)
+        else:
+            db = dout.sum(0)
     return dfe, dw, db
 
 
