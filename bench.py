@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--dense-dtype", default="f32", choices=["f32", "bf16", "f16"])
     ap.add_argument("--dense-layout", default="nhwc", choices=["nhwc", "nchw"], help="memory format of the BEV backbone")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen find mode)")
+    ap.add_argument("--no-miopen-db", action="store_true",
+                    help="do not load the tuned MIOpen user database shipped in tsm-det-pointcloud-_amd/miopen_db (solver "
+                         "choices of MIOpen's own tuner for the dense tail's convolutions; immediate mode then uses MIOpen's "
+                         "system database)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward / backbone / rulebook / Waymo extras")
@@ -603,6 +607,10 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the sparse hot path has no CPU fallback)"
+    miopen_db = None
+    if not args.no_miopen_db and not args.miopen_find:
+        from pcdet_amd.utils.miopen_db import use_tuned_db
+        miopen_db = use_tuned_db()          # before the first convolution of the process
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -669,6 +677,9 @@ def main():
                                     "fwd+bwd+AdamW step" if args.mode == "train" else "forward"),
                        "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": "dp%d" % world,
                        "voxelize_on_gpu": True,
+                       "miopen": ("immediate mode + the tuned user find/perf db shipped in miopen_db/ (written by MIOpen's own "
+                                  "tuner on these convolutions)" if miopen_db else
+                                  ("find mode" if args.miopen_find else "immediate mode, system db")),
                        "execution": "static row capacities, no host read in the step, rule tables on a second HIP stream"
                                     if caps is not None else "exact-size sparse tensors"},
         }
