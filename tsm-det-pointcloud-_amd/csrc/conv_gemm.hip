@@ -371,7 +371,8 @@ static int launch_mfma(const float* src, const float* wp, const int32_t* pair, i
   // 32->32 / 83 k rows; ablation: 22 us skeleton, +8 us gathers, +28..50 us LDS-read + MFMA phase at four waves per SIMD.
   // Not kept; profiles/r02_conv_experiments.md.)
   if constexpr (CS * CD <= 2048) {
-    if (n < (int64_t(1) << 18)) {        // low-channel layers: the latency form
+    if (n < (int64_t(1) << 19)) {        // low-channel layers: the latency form (measured against two tiles per wave at
+                                         // 140 k - 300 k live rows, also when the launch is sized by a 320 k-row static capacity)
       int64_t waves1 = (n + 15) / 16;
       hipLaunchKernelGGL((k_conv_mfma_sm<CS, CD>), dim3((unsigned)((waves1 + 3) / 4)), dim3(256), 0, s, src, wp, pair, ld, K,
                          flip, n, d_n, scale, shift, relu, dst);
