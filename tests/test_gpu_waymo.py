@@ -301,7 +301,7 @@ def test_cfg3_waymo_full_size_train_step_properties():
 def test_cfg5_waymo_concat_300k_voxels(orc):
     """BASELINE configs[4]: one 5-frame Waymo concatenation, ~600k points -> 300k voxels (cap 400k).  Voxeliser bit-exact;
     the 8 rule tables: subm1 + spconv2 bit-exact against the oracle, all of them through the size-independent properties;
-    16->16 and 64->64 layers (>= 2^18 rows: the MT=2 dispatch branch) forward / dgrad / wgrad vs the oracle + bitwise
+    16->16 and 64->64 layers (>= 2^18 rows: the MT=2 dispatch branch of the 64-channel kernels) forward / dgrad / wgrad vs the oracle + bitwise
     re-run; forward of the Waymo detector finite with the expected stage shapes."""
     from pcdet_amd.datasets import synthetic as syn
     from spx import ops
@@ -341,20 +341,22 @@ def test_cfg5_waymo_detector_forward_finite():
     assert bool(torch.isfinite(bd["batch_cls_preds"]).all())
 
 
-def test_million_row_dispatch_branches(orc):
-    """Row counts beyond anything the synthetic configs produce: >= 2^20 destination rows switches spx_conv_gemm to four
-    16-row tiles per wave (MT = 4), and a plan over more than 786k rows leaves the LDS-resident prefix of k_plan_scan.
-    Synthetic rule table (random neighbours, 10 % density), 16->16 through spx_conv_gemm and 64->64 through the balanced
-    schedule, against the numpy oracle; bitwise identical on a second launch."""
+@pytest.mark.parametrize("n,cases", [(600_000, ((16, 16, False),)), (1_100_000, ((16, 16, False), (64, 64, True)))])
+def test_million_row_dispatch_branches(n, cases, orc):
+    """Row counts beyond anything the synthetic configs produce: 2^19 <= rows < 2^20 switches the low-channel layers of
+    spx_conv_gemm from the latency form to two 16-row tiles per wave (MT = 2), >= 2^20 to four (MT = 4), and a plan over
+    more than 786k rows leaves the LDS-resident prefix of k_plan_scan.  Synthetic rule table (random neighbours, 10 %
+    density), 16->16 through spx_conv_gemm and 64->64 through the balanced schedule, against the numpy oracle; bitwise
+    identical on a second launch."""
     from spx import ops
     dev = _dev()
-    n, K = 1_100_000, 27
+    K = 27
     rs = np.random.RandomState(9)
     pair_np = np.where(rs.rand(K, n) < 0.10, rs.randint(0, n, size=(K, n)), -1).astype(np.int32)
     pair_np[13] = np.arange(n, dtype=np.int32)                    # the centre offset of a submanifold table
     pair = torch.from_numpy(pair_np).to(dev)
     g = torch.Generator().manual_seed(4)
-    for cs, cd, balanced in ((16, 16, False), (64, 64, True)):
+    for cs, cd, balanced in cases:
         x = torch.randn(n, cs, generator=g)
         w = torch.randn(cd, K, cs, generator=g) / np.sqrt(K * cs * 0.1)
         wp = ops.pack_weight(w.to(dev), 0)
