@@ -362,6 +362,58 @@ __global__ void k_conv_valu(const float* __restrict__ src, int CS, const float* 
   dst[row * CD + cd] = acc;
 }
 
+// ---------------------------------------------------------------- VALU, few source channels (the input layer: c_src = 4 / 5)
+// One thread per destination ROW holding all CD outputs in registers: the K rule entries and the few source floats of a
+// row are read once (k_conv_valu reads them once per output CHANNEL: 16 x the loads for conv_input), the [K][CS][CD]
+// weights sit in LDS and every lane reads the same word (broadcast).  Same summation order as k_conv_valu (offsets
+// ascending, source channels ascending, one fmaf chain per output): identical bits.
+template <int CD>
+__global__ __launch_bounds__(256) void k_conv_valu_rows(const float* __restrict__ src, int CS, const float* __restrict__ wp,
+                                                        const int32_t* __restrict__ pair, int64_t ld, int K, int flip,
+                                                        int64_t n, const int64_t* d_n, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int relu, float* __restrict__ dst) {
+  extern __shared__ float s_w[];                     // [K][CS][CD]
+  for (int i = threadIdx.x; i < K * CS * CD; i += 256) s_w[i] = wp[i];
+  __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= spx_live_n(d_n, n)) return;
+  float acc[CD];
+#pragma unroll
+  for (int c = 0; c < CD; ++c) acc[c] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 9) {
+    int32_t id[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int k = k0 + u < K ? k0 + u : K - 1;
+      id[u] = pair[(int64_t)(flip ? K - 1 - k : k) * ld + row];
+    }
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int k = k0 + u;
+      if (k >= K || id[u] < 0) continue;
+      const float* x = src + (size_t)id[u] * CS;
+      const float* ww = s_w + (size_t)k * CS * CD;
+      for (int cs = 0; cs < CS; ++cs) {
+        const float xv = x[cs];
+#pragma unroll
+        for (int c = 0; c < CD; ++c) acc[c] = fmaf(xv, ww[cs * CD + c], acc[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CD; c += 4) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = acc[c + e];
+      if (scale || shift) a = a * (scale ? scale[c + e] : 1.f) + (shift ? shift[c + e] : 0.f);
+      if (relu) a = a > 0.f ? a : 0.f;
+      v[e] = a;
+    }
+    *reinterpret_cast<f32x4*>(dst + row * CD + c) = v;
+  }
+}
+
 template <int CS, int CD>
 static int launch_mfma(const float* src, const float* wp, const int32_t* pair, int64_t ld, int K, int flip, int64_t n,
                        const int64_t* d_n, const float* scale, const float* shift, int relu, float* dst,
@@ -455,6 +507,18 @@ extern "C" int spx_conv_gemm(const float* src, int c_src, const float* w_packed,
     SPX_MFMA_CASE(16, 128)
     SPX_MFMA_CASE(128, 16)
     return SPX_ERR_UNSUPPORTED;  // unreachable: mfma_ok() admits exactly the 16 pairs above
+  }
+  if (c_src <= 8 && (c_dst == 16 || c_dst == 32) && (size_t)kvol * c_src * c_dst * sizeof(float) <= 48 * 1024) {
+    const unsigned nbr = (unsigned)((n_dst + 255) / 256);
+    const size_t lds = (size_t)kvol * c_src * c_dst * sizeof(float);
+    if (c_dst == 16)
+      hipLaunchKernelGGL((k_conv_valu_rows<16>), dim3(nbr), dim3(256), lds, s, src, c_src, w_packed, pair, pair_ld, kvol,
+                         flip_k, n_dst, d_n_dst, scale, shift, relu, dst);
+    else
+      hipLaunchKernelGGL((k_conv_valu_rows<32>), dim3(nbr), dim3(256), lds, s, src, c_src, w_packed, pair, pair_ld, kvol,
+                         flip_k, n_dst, d_n_dst, scale, shift, relu, dst);
+    SPX_CHECK_LAUNCH();
+    return SPX_OK;
   }
   int64_t total = n_dst * c_dst;
   unsigned nb = (unsigned)((total + 255) / 256);
