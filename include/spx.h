@@ -214,11 +214,14 @@ int spx_conv_gemm(const float *src, int c_src, const float *w_packed, int c_dst,
  * which is therefore not const: one launch per plan at a time — stream order is enough); partial sums are added in a fixed
  * order, so results are bitwise reproducible. */
 /* Optional row order for that schedule (csrc/conv_group.hip): a 16-row MFMA tile multiplies offset k for all its rows
- * as soon as one of them has it, so tiles whose rows share the same offsets issue fewer wasted MFMAs.  spx_conv_group
- * sorts the destination rows of a rule table by their offset mask (stable) and writes perm[n_dst] (position -> table row)
- * and pair_grouped[kvol][n_dst] = pair[k][perm[j]] (-1 beyond the live rows).  Build the plan over pair_grouped (ld =
- * n_dst) and pass pair_grouped + perm to spx_conv_gemm_balanced: position j is written to dst row perm[j].  Results do
- * not depend on the row order (every row is the same sum over k).  kvol <= 30. */
+ * as soon as one of them has it, so tiles whose rows share the same offsets issue fewer wasted MFMAs.  spx_conv_group orders
+ * the destination rows of a rule table by (window, group key) — windows = contiguous ranges of at most 4096 live rows, at
+ * least eight of them (one XCD's L2 then serves one part of the feature matrix); group key = an 11-bit digest of the row's
+ * offset mask (3x3x3: the nine in-plane offsets bit by bit, any offset in the plane below, any in the plane above) — stable
+ * (equal keys keep the table order; rows beyond the live count keep their place), with a hand-written counting sort, and
+ * writes perm[n_dst] (position -> table row) and pair_grouped[kvol][n_dst] = pair[k][perm[j]] (-1 beyond the live rows).
+ * Build the plan over pair_grouped (ld = n_dst) and pass pair_grouped + perm to spx_conv_gemm_balanced: position j is
+ * written to dst row perm[j].  Results do not depend on the row order (every row is the same sum over k).  kvol <= 30. */
 size_t spx_conv_group_ws_bytes(int64_t n_dst);
 int spx_conv_group(const int32_t *pair, int64_t pair_ld, int kvol, int64_t n_dst, const int64_t *d_n_dst, int32_t *perm,
                    int32_t *pair_grouped, void *ws, size_t ws_bytes, spx_stream_t stream);
