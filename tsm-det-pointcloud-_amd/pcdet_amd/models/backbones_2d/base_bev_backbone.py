@@ -15,7 +15,9 @@ from spx.functional import bn_relu_cat_train, bn_relu_train, dense as densify_ro
 
 # below this many activations the three-launch fused BN kernel is launch-bound and MIOpen's BN is faster (measured on
 # MI355X, tools/dense_tail_probe.py: 18 M elements 176 -> 132 us fwd+bwd, 9 M elements 98 -> 123 us)
-_FUSED_BN_MIN_ELEMS = int(os.environ.get("SPX_BEV_FUSED_BN_MIN", str(12 * 1024 * 1024)))
+# measured (round 2, alternating runs on one box): 8 M instead of 12 M elements brings the 256-channel KITTI maps (9.0 M)
+# in: +1.4 % of the cfg-2 step; 4 M / 2 M make no difference on the Waymo maps
+_FUSED_BN_MIN_ELEMS = int(os.environ.get("SPX_BEV_FUSED_BN_MIN", str(8 * 1000 * 1000)))
 
 
 def _run_block(seq, x, start=0):
