@@ -1,0 +1,88 @@
+"""Data-parallel training step on the HIP path with two ranks.  The GPU box has ONE MI355X, and RCCL refuses
+two ranks on one device, so the process group here is `gloo` carrying the GPU gradients (DDP stages them through the host):
+what this exercises on real hardware is everything around the collective — DistributedDataParallel over our autograd
+Functions, static row capacities, the index stream, one process per rank sharing the GPU — with frames sharded across the
+ranks.  The RCCL transport itself (backend "nccl") is what bench.py --gpus N uses on a multi-GPU node."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup_paths():
+    for p in (ROOT, os.path.join(ROOT, "tsm-det-pointcloud-_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _model_and_data():
+    from pcdet_amd.config import AttrDict, cfg_from_yaml_file
+    from pcdet_amd.datasets import SyntheticDataset
+    from pcdet_amd.models import build_network
+    cfg = cfg_from_yaml_file(os.path.join(ROOT, "tsm-det-pointcloud-_amd/tools/cfgs/kitti_models/second.yaml"), AttrDict())
+    ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, True, cfg_id=0, length=4)
+    torch.manual_seed(0)
+    model = build_network(cfg.MODEL, 3, ds)
+    return ds, model.train()
+
+
+def _batch(ds, fid, dev, static, model):
+    from pcdet_amd.models.inference import static_caps_for
+    b = ds.collate_batch([ds[fid]])
+    bd = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) and k != "frame_id" else v) for k, v in b.items()}
+    if static:
+        bd["static_caps"] = static_caps_for(model, 1, int(bd["points"].shape[0]),
+                                            level_factors={"spconv2": 6.0, "spconv3": 6.0, "spconv4": 4.0, "spconv_down2": 4.0})
+    return bd
+
+
+def _worker(rank, world, port, out_dir, static):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    from spx import ops
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    ds, model = _model_and_data()
+    model.to(dev)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, bucket_cap_mb=8, gradient_as_bucket_view=True)
+    ret, _tb, _ = ddp(_batch(ds, rank, dev, static, model))      # rank r trains on frame r (DistributedSampler-style)
+    ret["loss"].backward()
+    ops.check_status(dev)
+    grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters()}
+    torch.save({"loss": ret["loss"].detach().cpu(), "grads": grads}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("static", [False, True])
+def test_ddp_two_ranks_on_the_hip_path(tmp_path, static):
+    world, port = 2, 29600 + (os.getpid() % 2000) + (7 if static else 0)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), static), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=True)
+    for n in r0["grads"]:                       # after the all-reduce every rank holds the same (averaged) gradients
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n
+    assert float(r0["loss"]) != float(r1["loss"])            # different frames per rank (weak scaling)
+    # ... and they are the mean of the single-process gradients of frames 0 and 1 on the same kernels
+    _setup_paths()
+    dev = torch.device("cuda:0")
+    singles = []
+    for fid in (0, 1):
+        ds, model = _model_and_data()
+        model.to(dev)
+        ret, _tb, _ = model(_batch(ds, fid, dev, static, model))
+        ret["loss"].backward()
+        singles.append({n: p.grad.detach().cpu() for n, p in model.named_parameters()})
+    worst = 0.0
+    for n in singles[0]:
+        want = 0.5 * (singles[0][n] + singles[1][n])
+        worst = max(worst, float((r0["grads"][n] - want).abs().max() / want.abs().max().clamp_min(1e-12)))
+    assert worst < 1e-5, worst
