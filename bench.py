@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward / backbone / rulebook / Waymo extras")
+    ap.add_argument("--graph", action="store_true",
+                    help="single-GPU training: replay forward + backward as one hipGraph (GraphedTrainStep) instead of issuing "
+                         "them kernel by kernel; same rate on a fast host (the step is GPU-bound), insurance on a slow one")
     ap.add_argument("--dynamic", action="store_true",
                     help="training with exact-size sparse tensors (one host read per strided rule table) instead of the "
                          "host-sync-free static-capacity path")
@@ -137,12 +140,17 @@ class Step(object):
                     bd = m(bd)
             return bd["batch_box_preds"]
         self.sched.step(self.it)
-        self.opt.zero_grad(set_to_none=True)
-        if self.static_caps is not None:
-            bd["static_caps"] = self.static_caps
-        ret, _tb, _ = self.model(bd)
-        loss = ret["loss"].mean()
-        loss.backward()
+        if getattr(self, "graphed", None) is not None:
+            # forward + backward = one hipGraph replay (pcdet_amd/models/inference.py:GraphedTrainStep); gradients are
+            # rewritten in place by the replay, so no zero_grad
+            loss = self.graphed(batch["points"], batch["gt_boxes"])["loss"]
+        else:
+            self.opt.zero_grad(set_to_none=True)
+            if self.static_caps is not None:
+                bd["static_caps"] = self.static_caps
+            ret, _tb, _ = self.model(bd)
+            loss = ret["loss"].mean()
+            loss.backward()
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip, foreach=True)
         self.opt.step()
         self.it += 1
@@ -638,6 +646,13 @@ def main():
         core0 = model.module if hasattr(model, "module") else model
         caps = static_caps_for(core0, batch, max(int(b["points"].shape[0]) for b in batches), training=True)
     step = Step(model, optimizer, sched, cfg.OPTIMIZATION.GRAD_NORM_CLIP, args.mode, args.dense_dtype, static_caps=caps)
+    graphed = False
+    if caps is not None and world == 1 and args.graph and args.dense_dtype == "f32":
+        from pcdet_amd.models.inference import GraphedTrainStep
+        step.graphed = GraphedTrainStep(model, batch, max(int(b["points"].shape[0]) for b in batches) + 64,
+                                        max(int(b["gt_boxes"].shape[1]) for b in batches),
+                                        example=(batches[0]["points"], batches[0]["gt_boxes"]))
+        graphed = True
 
     for i in range(args.warmup):
         step(batches[i % len(batches)])
@@ -655,6 +670,8 @@ def main():
             sys.stderr.write("bench.py: %s -> falling back to exact-size tensors\n" % e)
             caps = None
             step.static_caps = None
+            step.graphed = None
+            graphed = False
             for i in range(max(args.warmup, 1)):
                 step(batches[i % len(batches)])
             torch.cuda.synchronize()
@@ -696,7 +713,8 @@ def main():
                        "miopen": ("immediate mode + the tuned user find/perf db shipped in miopen_db/ (written by MIOpen's own "
                                   "tuner on these convolutions)" if miopen_db else
                                   ("find mode" if args.miopen_find else "immediate mode, system db")),
-                       "execution": "static row capacities, no host read in the step, rule tables on a second HIP stream"
+                       "execution": ("static row capacities, no host read in the step, rule tables on a second HIP stream"
+                                     + ("; forward + backward replayed as one hipGraph, clip + AdamW eager" if graphed else ""))
                                     if caps is not None else "exact-size sparse tensors"},
         }
     # ---- roofline: instrumented extra steps of the same workload (rank 0 prints; all ranks run them so DDP stays in step)
@@ -706,6 +724,7 @@ def main():
         # algorithmic FLOPs / bytes need exact row counts on the host: the instrumented steps run the exact-size path (the
         # same kernels; at static capacity their grids only carry extra blocks that exit at once)
         step.static_caps = None
+        step.graphed = None
         n_inst = 3
         for i in range(n_inst):
             step(batches[i % len(batches)])

@@ -162,12 +162,23 @@ class AnchorHeadTemplate(nn.Module):
             tb_dict['rpn_loss_dir'] = dir_loss.detach()
         return box_loss, tb_dict
 
+    def _unit_code_weights(self, rl):
+        """code_weights are a constant of the config: read them once, not per step (a host read of device memory would
+        put a sync in every training step and cannot be captured in a hipGraph)."""
+        cw = rl.code_weights
+        if cw is None:
+            return True
+        key = (cw.data_ptr(), cw._version)
+        if getattr(self, '_cw_key', None) != key:
+            self._cw_key, self._cw_unit = key, bool((cw == 1).all())
+        return self._cw_unit
+
     def _fused_loss_ok(self):
         fr = self.forward_ret_dict
         rl = self.reg_loss_func
         return (fr['cls_preds'].is_cuda and type(rl) is loss_utils.WeightedSmoothL1Loss and self.num_class <= 8
                 and fr['box_cls_labels'].dtype == torch.int32 and self.box_coder.code_size == 7
-                and (rl.code_weights is None or bool((rl.code_weights == 1).all()))
+                and self._unit_code_weights(rl)
                 and not self.use_multihead and self.num_class > 1)
 
     def get_loss_fused(self):

@@ -106,3 +106,74 @@ class GraphedDetector(object):
     def post_process(self):
         """score threshold + NMS on the last outputs (data dependent: outside the graph)."""
         return self.model.post_processing(dict(self.out))
+
+
+class GraphedTrainStep(object):
+    """Forward + backward of one training step as ONE hipGraph replay (single process; data-parallel ranks stay eager: DDP's
+    bucket hooks and the RCCL all-reduce are not captured here).
+
+    The training step issues ~750 kernels; at static row capacities none of them needs the host, so the whole
+    forward + backward — voxeliser, index stream, sparse and dense convolutions, losses, every gradient — is captured
+    once and replayed per step.  The host then issues a copy of the batch into the static buffers, one replay, gradient
+    clipping and the (fused) optimizer step: the reference's loop (tools/train_utils/train_utils.py:44-56: zero_grad,
+    model_func, backward, clip_grad_norm_, optimizer.step) with its first three calls folded into the replay.  Parameter
+    gradients live in the graph's memory pool and are rewritten by every replay, so there is no zero_grad between steps.
+
+    points [N, 1+C] (frame index in column 0, frames ascending), gt_boxes [B, M, 8]; N <= max_points, M <= max_gt."""
+
+    def __init__(self, model, batch_size, max_points, max_gt, level_factors=None, warmup=3, example=None):
+        assert model.training, "GraphedTrainStep captures the training forward"
+        self.model = model
+        self.batch_size = int(batch_size)
+        self.device = next(model.parameters()).device
+        vfe = model.vfe
+        c = 1 + vfe.num_point_features
+        self.max_points, self.max_gt = int(max_points), int(max_gt)
+        self.points = torch.empty((self.max_points, c), dtype=torch.float32, device=self.device)
+        self._pad_row = torch.zeros((c,), dtype=torch.float32, device=self.device)
+        self._pad_row[0] = self.batch_size - 1
+        self._pad_row[1] = float(vfe.point_cloud_range[0]) - 1.0e4          # outside the range: dropped by the voxeliser
+        self.points[:] = self._pad_row
+        self.gt_boxes = torch.zeros((self.batch_size, self.max_gt, 8), dtype=torch.float32, device=self.device)
+        self.static_caps = static_caps_for(model, self.batch_size, self.max_points, training=True,
+                                           level_factors=level_factors)
+        if example is not None:
+            self._load(example[0], example[1])
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):                      # allocator pools, workspaces, MIOpen kernel selection
+                model.zero_grad(set_to_none=True)
+                self._forward_backward()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        model.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._forward_backward()
+
+    def _forward_backward(self):
+        bd = {'points': self.points, 'gt_boxes': self.gt_boxes, 'batch_size': self.batch_size,
+              'static_caps': self.static_caps}
+        ret, tb_dict, _disp = self.model(bd)
+        loss = ret['loss'].mean()
+        loss.backward()
+        return {'loss': loss.detach(), 'tb_dict': tb_dict}
+
+    def _load(self, points, gt_boxes):
+        n, m = points.shape[0], gt_boxes.shape[1]
+        if n > self.max_points or m > self.max_gt or gt_boxes.shape[0] != self.batch_size:
+            raise ValueError("batch (%d points, %d boxes) exceeds the captured capacities (%d, %d)"
+                             % (n, m, self.max_points, self.max_gt))
+        self.points[:n].copy_(points, non_blocking=True)
+        if n < self.max_points:
+            self.points[n:] = self._pad_row
+        self.gt_boxes.zero_()
+        self.gt_boxes[:, :m].copy_(gt_boxes, non_blocking=True)
+
+    def __call__(self, points, gt_boxes):
+        """Copies the batch in and replays forward + backward; parameter .grad tensors hold the new gradients afterwards.
+        Returns the static output dict {'loss', 'tb_dict'} (overwritten by the next call)."""
+        self._load(points, gt_boxes)
+        self.graph.replay()
+        return self.out
