@@ -361,6 +361,25 @@ int spx_bn_apply(const float *x, const float *res, int64_t n, const int64_t *d_n
                  spx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 9b. Dense 3x3 / stride 1 / pad 1 convolution of the BEV backbone, Winograd F(2x2, 3x3) on the exact-fp32 MFMA
+ *    replaces: nn.Conv2d(c, c, kernel_size=3, padding=1, bias=False) forward and its data gradient, reference
+ *    pcdet/models/backbones_2d/base_bev_backbone.py:38-49 (cuDNN / MIOpen implicit GEMM: 9 multiplies per (pixel, ci, co)
+ *    against 4 here).  Maps are channels-last: pixel p = (n*H + y)*W + x, channel c at x[p * x_ld + c].
+ *
+ * spx_wino_weight: weight element (co, ci, a, b) at w[co*s_o + ci*s_i + a*s_a + b*s_b] (strides in floats: OIHW or
+ *    channels_last) -> the transformed, fragment-ordered image u (spx_wino_weight_floats(cin, cout) floats).
+ *    flip = 0: forward filter, cin/cout = the layer's.  flip = 1: filter of the data gradient — pass cin = the layer's
+ *    Cout and cout = the layer's Cin; taps are rotated by 180 degrees and the channel roles swapped inside.
+ *    cin % 32 == 0 and cout % 128 == 0, else SPX_ERR_INVALID_ARG.
+ * spx_conv2d_wino: y = conv3x3(x) with optional epilogue y = relu?(y * scale[co] + shift[co]) (eval BatchNorm folded to
+ *    scale/shift; null = identity).  x_ld >= cin, y_ld >= cout, both multiples of 4; x, y 16-byte aligned. */
+int64_t spx_wino_weight_floats(int32_t cin, int32_t cout);
+int spx_wino_weight(const float *w, int64_t s_o, int64_t s_i, int64_t s_a, int64_t s_b, int32_t cin, int32_t cout, int flip,
+                    float *u, spx_stream_t stream);
+int spx_conv2d_wino(const float *x, int64_t x_ld, const float *u, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                    const float *scale, const float *shift, int relu, float *y, int64_t y_ld, spx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * 10. Voxel query (consumers of multi_scale_3d_features)
  *    replaces: pointnet2_stack_cuda.voxel_query_wrapper, reference
  *      pcdet/ops/pointnet2/pointnet2_stack/src/voxel_query_gpu.cu:10-122 (python side voxel_query_utils.py:12-50).

@@ -1,0 +1,176 @@
+"""Winograd F(2x2, 3x3) dense convolution (csrc/wino_conv2d.hip) against a float64 direct convolution on the CPU.
+
+Bar: |err| <= 2e-5 * max(1, max|ref|), the same as the sparse fp32-MFMA convolutions: arithmetic is fp32 throughout, the
+transform only re-associates the sum (measured ~1e-6 * scale at 128..256 input channels).  torch's fp32 conv2d on the same
+GPU (MIOpen, direct form) is checked against the same reference beside it, so the two error levels can be compared.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _ref(x, w, scale=None, shift=None, relu=False):
+    y = F.conv2d(x.double().cpu(), w.double().cpu(), padding=1)
+    if scale is not None:
+        y = y * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
+    if relu:
+        y = torch.relu(y)
+    return y
+
+
+def _check(y, ref, tol=TOL):
+    ref = ref.numpy()
+    err = float(np.abs(y.double().cpu().numpy() - ref).max())
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert err <= tol * scale, "max|err| %.3e > %.1e * %.3g" % (err, tol, scale)
+    return err / scale
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(1, 8, 8, 32, 128), (1, 7, 9, 64, 128), (2, 20, 18, 96, 256), (3, 5, 3, 32, 128),
+                                             (1, 1, 1, 32, 128), (2, 33, 17, 128, 128), (1, 26, 22, 256, 256)])
+def test_forward_matches_direct_conv(n, h, w, cin, cout):
+    from spx import ops
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + w)
+    x = torch.randn((n, cin, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(9 * cin)).cuda()
+    y = ops.conv2d_wino(x, ops.wino_weight(wt), cout)
+    assert y.shape == (n, cout, h, w) and y.is_contiguous(memory_format=torch.channels_last)
+    ref = _ref(x, wt)
+    e_w = _check(y, ref)
+    e_t = _check(F.conv2d(x, wt, padding=1), ref)
+    print("rel err wino %.2e  vendor direct %.2e" % (e_w, e_t))
+
+
+def test_channels_last_weight_and_epilogue():
+    from spx import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 32, 10, 12), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn((128, 32, 3, 3), generator=g) / 12).cuda().contiguous(memory_format=torch.channels_last)
+    sc = (torch.rand((128,), generator=g) + 0.5).cuda()
+    sh = torch.randn((128,), generator=g).cuda()
+    y = ops.conv2d_wino(x, ops.wino_weight(wt), 128, scale=sc, shift=sh, relu=True)
+    _check(y, _ref(x, wt, sc, sh, True))
+
+
+def test_row_strided_input_and_output():
+    """x is a channel slice of a wider map, y is written into a channel slice of a wider map (the concatenated BEV map)."""
+    from spx import ops
+    g = torch.Generator().manual_seed(6)
+    big = torch.randn((2, 96, 9, 11), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    x = big[:, 32:64]
+    wt = (torch.randn((128, 32, 3, 3), generator=g) / 12).cuda()
+    out_big = torch.full((2, 384, 9, 11), 7.0).cuda().contiguous(memory_format=torch.channels_last)
+    ops.conv2d_wino(x, ops.wino_weight(wt), 128, out=out_big[:, 128:256])
+    _check(out_big[:, 128:256], _ref(x, wt))
+    assert float(out_big[:, :128].min()) == 7.0 and float(out_big[:, 256:].max()) == 7.0
+
+
+def test_data_gradient_image():
+    """conv2d_wino(dy, wino_weight(w, flip=True)) is the data gradient of conv2d(x, w, padding=1)."""
+    from spx import ops
+    g = torch.Generator().manual_seed(7)
+    cin, cout = 128, 32
+    wt = (torch.randn((cout, cin, 3, 3), generator=g) / 12).cuda()
+    dy = torch.randn((2, cout, 12, 14), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    dx = ops.conv2d_wino(dy, ops.wino_weight(wt, flip=True), cin)
+    x = torch.zeros((2, cin, 12, 14), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, wt.double().cpu(), padding=1).backward(dy.double().cpu())
+    _check(dx, x.grad)
+
+
+def test_kitti_bev_shape_linearity_and_vendor_agreement():
+    """Full BEV size of BASELINE configs[1] (4 x 128 x 200 x 176): agreement with the vendor convolution and linearity."""
+    from spx import ops
+    g = torch.Generator().manual_seed(8)
+    x1 = torch.randn((4, 128, 200, 176), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    x2 = torch.randn((4, 128, 200, 176), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn((128, 128, 3, 3), generator=g) / np.sqrt(9 * 128)).cuda()
+    u = ops.wino_weight(wt)
+    y1, y2 = ops.conv2d_wino(x1, u, 128), ops.conv2d_wino(x2, u, 128)
+    y12 = ops.conv2d_wino(x1 + 2 * x2, u, 128)
+    scale = float(y12.abs().max())
+    assert float((y12 - (y1 + 2 * y2)).abs().max()) <= TOL * scale
+    assert float((y1 - F.conv2d(x1, wt, padding=1)).abs().max()) <= TOL * scale
+
+
+def test_rejects_unsupported_channels():
+    from spx import ops
+    wt = torch.zeros((64, 32, 3, 3)).cuda()
+    assert not ops.wino_ok(32, 64) and ops.wino_ok(32, 128) and not ops.wino_ok(8, 128)
+    with pytest.raises(RuntimeError):
+        ops.wino_weight(wt)
+
+
+def test_autograd_matches_vendor_conv():
+    """_WinoConv2dFn: output, data gradient (Winograd kernel with the flipped image) and weight gradient (vendor wrw)
+    against torch's conv2d autograd in float64."""
+    from spx.functional import wino_conv2d
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((2, 128, 14, 18), generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn((128, 128, 3, 3), generator=g) / 34).cuda().requires_grad_(True)
+    dy = torch.randn((2, 128, 14, 18), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    y = wino_conv2d(x, w)
+    y.backward(dy)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    wr = w.detach().double().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, padding=1)
+    yr.backward(dy.double().cpu())
+    _check(y.detach(), yr.detach())
+    _check(x.grad, xr.grad)
+    _check(w.grad, wr.grad, tol=5e-5)
+
+
+def _bev(train):
+    from pcdet_amd.config import AttrDict as EasyDict
+    from pcdet_amd.models.backbones_2d.base_bev_backbone import BaseBEVBackbone
+    cfg = EasyDict(LAYER_NUMS=[2, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[128, 256], UPSAMPLE_STRIDES=[1, 2],
+                   NUM_UPSAMPLE_FILTERS=[256, 256])
+    torch.manual_seed(3)
+    m = BaseBEVBackbone(cfg, 64).cuda().to(memory_format=torch.channels_last)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.1)
+    return m.train(train)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_bev_backbone_with_and_without_winograd(train):
+    """BaseBEVBackbone forward (and, training, every parameter gradient) with the Winograd rewrite on and off."""
+    import pcdet_amd.models.backbones_2d.base_bev_backbone as bb
+    m = _bev(train)
+    x = torch.randn((2, 64, 24, 20), generator=torch.Generator().manual_seed(4)).cuda().contiguous(memory_format=torch.channels_last)
+    outs, grads = [], []
+    for flag in (False, True):
+        bb._WINO = flag
+        try:
+            for p in m.parameters():
+                p.grad = None
+            if train:
+                # identical running statistics for both passes
+                state = {k: v.clone() for k, v in m.state_dict().items()}
+                y = m({'spatial_features': x})['spatial_features_2d']
+                (y * torch.linspace(0.5, 1.5, y.numel(), device='cuda').view_as(y)).sum().backward()
+                grads.append([p.grad.clone() for p in m.parameters()])
+                m.load_state_dict(state)
+            else:
+                with torch.no_grad():
+                    y = m({'spatial_features': x})['spatial_features_2d']
+            outs.append(y.detach().clone())
+        finally:
+            bb._WINO = True
+    scale = float(outs[0].abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-4 * scale
+    if train:
+        # train-mode BatchNorm makes every conv's weight gradient a difference of large, nearly cancelling terms, so fp32
+        # re-association upstream shows amplified here (same bar as the static-vs-dynamic train-step test)
+        worst = max(float((a - b).abs().max()) / max(1e-3, float(a.abs().max())) for a, b in zip(*grads))
+        print("worst relative parameter-gradient difference %.2e" % worst)
+        assert worst <= 2e-2

@@ -1,0 +1,359 @@
+// wino_conv2d.hip — dense 3x3 / stride 1 / pad 1 convolution over channels-last BEV maps, Winograd F(2x2, 3x3) on the
+// exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), transforms fused into the one kernel.
+//
+// Replaces, for the 3x3 stride-1 layers of BaseBEVBackbone (reference pcdet/models/backbones_2d/base_bev_backbone.py:38-49:
+// Conv2d(c, c, kernel_size=3, padding=1, bias=False) x LAYER_NUMS per block) the vendor implicit-GEMM kernels that take
+// 2/3 of the training step: the direct form needs 9 multiplies per (pixel, ci, co), F(2x2, 3x3) needs 4 — per 2x2 output
+// tile, 16 element-wise products in the transformed domain, each of them a [tiles x Cin] x [Cin x Cout] GEMM:
+//     Y = A^T [ (G g G^T) . (B^T d B) ] A          (Lavin & Gray 2015, correlation form — what Conv2d computes)
+// The data gradient is the same kernel over dY with the taps rotated by 180 degrees and ci/co swapped (spx_wino_weight's
+// `flip`).  Arithmetic stays fp32 end to end (the transforms are +/- and *0.5, the products run on the f32 MFMA); the
+// difference to the direct sum is reassociation, ~1e-6 relative (tests/test_gpu_wino.py states the bar).
+//
+// Work decomposition (one workgroup = 512 threads = 8 waves, 2 per SIMD):
+//   * 32 consecutive 2x2 tiles (row-major over frame, tile row, tile column) x 128 output channels;
+//   * wave (w, half): the 4 transform positions of row i = w (p = 4w .. 4w+3), output channels half*64 .. +63:
+//     accumulators 4 positions x 2 column blocks x 16 = 128 registers; A = transformed input (tiles are the MFMA rows),
+//     B = transformed weights (output channels are the MFMA columns);
+//   * K loop in chunks of 8 input channels: threads 0..255 load one column (4 pixels x 4 channels) of one tile's 4x4 input
+//     patch straight from global memory (the 4x overlap of neighbouring patches is served by L1/L2), transform it (column
+//     pass in registers, row pass across the 4 lanes of a quad with DPP) and write the 16 positions to LDS, double
+//     buffered; every wave reads its A fragments back with ds_read_b128.  B fragments never touch LDS: a position's
+//     weights are used by exactly one wave, which reads them from the (L2-resident, pre-transformed, fragment-ordered)
+//     weight image with one coalesced 1 KiB load per (position, column block);
+//   * the k index of an MFMA step is (lane half h, sub-step s) -> channel 4h+s for A and B alike, so one 16-byte load
+//     feeds four MFMA steps;
+//   * output transform: each wave reduces its row over j in registers ((M A)[i][c], c = 0,1), the four rows meet in LDS
+//     (64 KiB per c) and all 512 threads combine them, apply the optional per-channel scale / shift / ReLU and store
+//     channels-last rows (512 contiguous bytes per pixel).
+#include "spx_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kTiles = 32;    // 2x2 output tiles per workgroup = MFMA rows
+constexpr int kKc = 8;        // input channels per K chunk
+constexpr int kSc = 32;       // input channels per super-chunk (4 chunks): one 128-byte line of a pixel
+constexpr int kCoWg = 128;    // output channels per workgroup
+constexpr int kThreads = 512;
+constexpr int kPosFloats = kCoWg * kKc;   // floats of one (chunk, position) of the weight image
+
+struct WinoArgs {
+  const float* x;      // [N, H, W] pixels, x_ld floats apart, Cin used
+  const float* u;      // transformed weights, see k_wino_weight
+  float* y;            // [N, H, W] pixels, y_ld floats apart
+  const float* scale;  // [Cout] or null
+  const float* shift;  // [Cout] or null
+  int64_t x_ld, y_ld;
+  int32_t n, h, w, cin, cout;
+  int32_t tiles_x, tiles_y;
+  int64_t n_tiles;
+  int32_t relu;
+  int32_t n_blocks;    // gridDim.x
+};
+
+// quad_perm[a,b,c,d] DPP control
+constexpr int qp(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+
+__device__ __forceinline__ float dpp_p(float v) {   // lanes (0,1,2,3) of a quad read lanes (0,1,2,1)
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), qp(0, 1, 2, 1), 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_q(float v) {   // lanes (0,1,2,3) of a quad read lanes (2,2,1,3)
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), qp(2, 2, 1, 3), 0xF, 0xF, true));
+}
+
+// Which input channel sits in k-slot `slot` (0..7) of chunk `chunk`.  A loader lane fetches 16 bytes (4 channels) per
+// pixel and 128-byte half; chunk kk of a super-chunk takes component kk of every such fetch, so the 8 k-slots of a chunk
+// are channels 32*S + 16*e + 4*g + kk  (g = slot >> 1: lane group, e = slot & 1: 64-byte half) — see the loader below.
+__host__ __device__ constexpr int wino_channel(int chunk, int slot) {
+  return (chunk >> 2) * kSc + (slot & 1) * 16 + (slot >> 1) * 4 + (chunk & 3);
+}
+
+// Transformed weight image u[cb][chunk][pos 16][nb 4][h 2][col 32][s 4]: cb = output-channel block of 128, nb = 32-column
+// block, k-slot = 4h + s — the 1 KiB of one (chunk, pos, nb) is exactly one wave's B-fragment load in lane order.
+// U_pos = (G g G^T)[pos] with g[a][b] = w[(co, ci, a, b)] (flip = 0) or w[(ci', co', 2-a, 2-b)] read as the filter of the
+// data gradient (flip = 1: the kernel's "input channels" are the layer's output channels).  Strides are in floats, so
+// OIHW-contiguous and channels_last weights both work.
+__global__ void k_wino_weight(const float* __restrict__ w, int64_t s_o, int64_t s_i, int64_t s_a, int64_t s_b, int cin,
+                              int cout, int flip, float* __restrict__ u) {
+  // cin / cout are the KERNEL's input / output channel counts (already swapped by the host for flip = 1)
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)cin * cout;
+  if (idx >= total) return;
+  const int nchunk = cin / kKc;
+  const int sidx = (int)(idx & 3);
+  const int col = (int)((idx >> 2) & 31);
+  const int hh = (int)((idx >> 7) & 1);
+  const int nb = (int)((idx >> 8) & 3);
+  const int chunk = (int)((idx >> 10) % nchunk);
+  const int cb = (int)((idx >> 10) / nchunk);
+  const int ci = wino_channel(chunk, 4 * hh + sidx), co = cb * kCoWg + nb * 32 + col;
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      g[a][b] = flip ? w[(int64_t)ci * s_o + (int64_t)co * s_i + (2 - a) * s_a + (2 - b) * s_b]
+                     : w[(int64_t)co * s_o + (int64_t)ci * s_i + a * s_a + b * s_b];
+  float t[4][3];   // G g
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+    t[3][b] = g[2][b];
+  }
+  float* dst = u + ((int64_t)(cb * nchunk + chunk) * 16) * kPosFloats + (idx & 1023);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dst[(int64_t)(i * 4 + 0) * kPosFloats] = t[i][0];
+    dst[(int64_t)(i * 4 + 1) * kPosFloats] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+    dst[(int64_t)(i * 4 + 2) * kPosFloats] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+    dst[(int64_t)(i * 4 + 3) * kPosFloats] = t[i][2];
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
+  // V[buf 2][pos 16][tile 32][k 8] during the K loop (32 KiB); R[row i 4][tile 32][co 128] in the output transform (64 KiB)
+  __shared__ __attribute__((aligned(16))) float smem[4 * kTiles * kCoWg];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wrow = wave & 3;    // transform row i owned by this wave
+  const int half = wave >> 2;   // output-channel half (64) of the workgroup's 128
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // XCD-aware placement: consecutive workgroup ids go to different XCDs; give each XCD a contiguous range of tile blocks
+  // so that the halo pixels two neighbouring blocks share are served by one L2
+  int bid = blockIdx.x;
+  {
+    const int per = a.n_blocks >> 3;
+    if (per > 0 && bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int64_t tile0 = (int64_t)bid * kTiles;
+  const int cb = blockIdx.y;
+  const int nchunk = a.cin / kKc;
+  const int nsuper = a.cin / kSc;
+
+  // ---- loader role (every thread): one patch column (4 pixels) of one tile, lane group g of 4.  Per super-chunk (32
+  // channels = one 128-byte line of each pixel) a thread fetches, for each of its 4 pixels, 16 bytes of the line's first
+  // half and 16 of its second (channels 4g..4g+3 and 16+4g..16+4g+3): the four lane groups of a pixel cover 64 contiguous
+  // bytes per instruction and every fetched line is used completely, once.  Component kk of the eight fetched vectors is
+  // the thread's share of chunk kk of the super-chunk (wino_channel), so one round of loads feeds four K chunks.
+  const int ld_col = tid & 3;           // patch column j — the 4 lanes of a DPP quad
+  const int ld_g = (tid >> 2) & 3;      // lane group: channels 4g..4g+3 of each 64-byte half
+  const int ld_tile = tid >> 4;         // tile inside the workgroup
+  const float* xrow[4];
+  float xmask[4];
+  {
+    const int64_t t = tile0 + ld_tile;
+    const bool tv = t < a.n_tiles;
+    const int64_t tt = tv ? t : 0;
+    const int tx = (int)(tt % a.tiles_x);
+    const int ty = (int)((tt / a.tiles_x) % a.tiles_y);
+    const int nn = (int)(tt / ((int64_t)a.tiles_x * a.tiles_y));
+    const int px = 2 * tx - 1 + ld_col;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int py = 2 * ty - 1 + i;
+      const bool ok = tv && px >= 0 && px < a.w && py >= 0 && py < a.h;
+      // out-of-map pixels (the zero padding) read pixel 0 and are multiplied by 0: every lane issues every load, so the
+      // number of loads in flight is the same on all paths and the compiler can wait for exactly the ones it needs
+      const int64_t pix = ok ? ((int64_t)nn * a.h + py) * a.w + px : 0;
+      xmask[i] = ok ? 1.0f : 0.0f;
+      xrow[i] = a.x + pix * a.x_ld + ld_g * 4;
+    }
+  }
+  const float sgn = (ld_col == 1) ? 1.0f : -1.0f;
+  float* const vdst = smem + (ld_col * kTiles + ld_tile) * kKc + ld_g * 2;   // + buf*16*32*8 + i*4*32*8
+
+  // ---- MFMA role
+  // weights of this wave: positions 4*wrow .. +3, column blocks 2*half, 2*half+1 of block cb
+  const float* const ubase = a.u + (((int64_t)cb * nchunk * 16 + wrow * 4) * 4 + half * 2) * 256 + lane * 4;
+  const float* const asrc = smem + (wrow * 4 * kTiles + l31) * kKc + lh * 4;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][nb][r] = 0.f;
+
+  f32x4 xr[4][2];   // [patch row][64-byte half]
+  auto load_x = [&](int sc) {
+    sc = sc < nsuper ? sc : nsuper - 1;   // past the end: repeat the last one (loaded, never used)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xr[i][0] = *reinterpret_cast<const f32x4*>(xrow[i] + sc * kSc);
+      xr[i][1] = *reinterpret_cast<const f32x4*>(xrow[i] + sc * kSc + 16);
+    }
+  };
+  // transforms chunk kk of the super-chunk in xr into V buffer `buf`
+  auto transform_store = [&](int buf, int kk) {
+    f32x2 d[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = f32x2{xr[i][0][kk], xr[i][1][kk]} * xmask[i];
+    // column pass (over patch rows): t = B^T d
+    f32x2 t[4];
+    t[0] = d[0] - d[2];
+    t[1] = d[1] + d[2];
+    t[2] = d[2] - d[1];
+    t[3] = d[1] - d[3];
+    // row pass across the quad's lanes: lane j' gets (t B)[i][j']
+    float* dst = vdst + buf * (16 * kTiles * kKc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x2 v;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) v[e] = dpp_p(t[i][e]) + sgn * dpp_q(t[i][e]);
+      *reinterpret_cast<f32x2*>(dst + i * (4 * kTiles * kKc)) = v;
+    }
+  };
+  // B fragments of the current chunk; position j's pair is re-loaded for the NEXT chunk right after the MFMAs that read it
+  // were issued, so a chunk's weight fetch has a whole chunk of MFMAs to land in and only 8 fragment registers per
+  // position are live
+  f32x4 bw[4][2];
+  auto load_b = [&](int chunk, int j) {
+    chunk = chunk < nchunk ? chunk : nchunk - 1;   // the last chunk re-reads itself: constant load count per iteration
+    const float* p = ubase + (int64_t)chunk * 16 * kPosFloats + j * kPosFloats;
+    bw[j][0] = *reinterpret_cast<const f32x4*>(p);
+    bw[j][1] = *reinterpret_cast<const f32x4*>(p + 256);
+  };
+  auto mma = [&](int buf, int next_chunk) {
+    const float* s = asrc + buf * (16 * kTiles * kKc);
+    f32x4 av[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(s + j * (kTiles * kKc));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][st], bw[j][nb][st], acc[j][nb], 0, 0, 0);
+      load_b(next_chunk, j);
+      // keep the re-load HERE: left alone, the scheduler sinks all eight loads below the last MFMA of the chunk and the
+      // next chunk then starts by waiting out their L2 latency
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // prologue: chunk 0 into buffer 0.  Issue order as in the loop (x, then the weights): loads retire in order, and the
+  // loop's waits for x must find the weight loads YOUNGER than what they wait for on every path into the loop.
+  load_x(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load_b(0, j);
+  transform_store(0, 0);
+  __syncthreads();
+
+  // One barrier per chunk: iteration c multiplies chunk c out of buffer c&1 while chunk c+1 is transformed into the other
+  // buffer (last read in iteration c-1, i.e. before the barrier that ended it).  The x registers of super-chunk S are
+  // dead after chunk 4S+3 has been transformed (iteration 4S+2); super-chunk S+1 is fetched right there and first used
+  // one iteration later.  The transform after the last chunk rewrites a buffer nobody reads again.
+  for (int sc = 0; sc < nsuper; ++sc) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = sc * 4 + kk;
+      transform_store((kk & 1) ^ 1, (kk + 1) & 3);
+      if (kk == 2) load_x(sc + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(kk & 1, c + 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- output transform.  This wave holds M[i = wrow][j = 0..3]; (M A)[i][0] = M0 + M1 + M2, (M A)[i][1] = M1 - M2 - M3;
+  // Y[0][c] = R0 + R1 + R2, Y[1][c] = R1 - R2 - R3 over the four rows i (= waves), which meet in LDS.
+  const int o_q = tid & 31;          // output-channel quad
+  const int o_t = tid >> 5;          // tile 0..15 (+16 in the second pass)
+  const int co0 = cb * kCoWg + o_q * 4;
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.scale) sc4 = *reinterpret_cast<const f32x4*>(a.scale + co0);
+  if (a.shift) sh4 = *reinterpret_cast<const f32x4*>(a.shift + co0);
+#pragma unroll
+  for (int c2 = 0; c2 < 2; ++c2) {
+    float* r = smem + (wrow * kTiles) * kCoWg + half * 64 + l31;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int trow = (g & 3) + 8 * (g >> 2) + 4 * lh;
+        const float v = (c2 == 0) ? (acc[0][nb][g] + acc[1][nb][g] + acc[2][nb][g])
+                                  : (acc[1][nb][g] - acc[2][nb][g] - acc[3][nb][g]);
+        r[trow * kCoWg + nb * 32] = v;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int tl = o_t + ps * 16;
+      const int64_t t = tile0 + tl;
+      const float* s = smem + tl * kCoWg + o_q * 4;
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(s);
+      const f32x4 r1 = *reinterpret_cast<const f32x4*>(s + kTiles * kCoWg);
+      const f32x4 r2 = *reinterpret_cast<const f32x4*>(s + 2 * kTiles * kCoWg);
+      const f32x4 r3 = *reinterpret_cast<const f32x4*>(s + 3 * kTiles * kCoWg);
+      if (t < a.n_tiles) {
+        const int tx = (int)(t % a.tiles_x);
+        const int ty = (int)((t / a.tiles_x) % a.tiles_y);
+        const int nn = (int)(t / ((int64_t)a.tiles_x * a.tiles_y));
+        const int px = 2 * tx + c2;
+        f32x4 y0 = (r0 + r1 + r2) * sc4 + sh4;
+        f32x4 y1 = (r1 - r2 - r3) * sc4 + sh4;
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            y0[e] = fmaxf(y0[e], 0.f);
+            y1[e] = fmaxf(y1[e], 0.f);
+          }
+        }
+        if (px < a.w) {
+          const int py = 2 * ty;
+          float* dst = a.y + (((int64_t)nn * a.h + py) * a.w + px) * a.y_ld + co0;
+          *reinterpret_cast<f32x4*>(dst) = y0;
+          if (py + 1 < a.h) *reinterpret_cast<f32x4*>(dst + (int64_t)a.w * a.y_ld) = y1;
+        }
+      }
+    }
+    if (c2 == 0) __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t spx_wino_weight_floats(int32_t cin, int32_t cout) { return (int64_t)16 * cin * cout; }
+
+extern "C" int spx_wino_weight(const float* w, int64_t s_o, int64_t s_i, int64_t s_a, int64_t s_b, int32_t cin, int32_t cout,
+                               int flip, float* u, spx_stream_t stream) {
+  if (cin <= 0 || cout <= 0 || cin % kSc != 0 || cout % kCoWg != 0) return SPX_ERR_INVALID_ARG;
+  const int64_t total = (int64_t)cin * cout;
+  hipLaunchKernelGGL(k_wino_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, spx_s(stream), w, s_o, s_i, s_a,
+                     s_b, cin, cout, flip, u);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}
+
+extern "C" int spx_conv2d_wino(const float* x, int64_t x_ld, const float* u, int32_t n, int32_t h, int32_t w, int32_t cin,
+                               int32_t cout, const float* scale, const float* shift, int relu, float* y, int64_t y_ld,
+                               spx_stream_t stream) {
+  if (n <= 0 || h <= 0 || w <= 0) return SPX_OK;
+  if (cin % kSc != 0 || cout % kCoWg != 0 || x_ld < cin || y_ld < cout || (x_ld & 3) || (y_ld & 3)) return SPX_ERR_INVALID_ARG;
+  WinoArgs a;
+  a.x = x; a.u = u; a.y = y; a.scale = scale; a.shift = shift;
+  a.x_ld = x_ld; a.y_ld = y_ld;
+  a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+  a.tiles_x = (w + 1) / 2; a.tiles_y = (h + 1) / 2;
+  a.n_tiles = (int64_t)n * a.tiles_x * a.tiles_y;
+  a.relu = relu;
+  const int64_t nb = (a.n_tiles + kTiles - 1) / kTiles;
+  if (nb > 0x7fffffff) return SPX_ERR_INVALID_ARG;
+  a.n_blocks = (int32_t)nb;
+  hipLaunchKernelGGL(k_wino_conv, dim3((unsigned)nb, (unsigned)(cout / kCoWg)), dim3(kThreads), 0, spx_s(stream), a);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}

@@ -331,3 +331,72 @@ def bn_act(x, bn, relu, residual=None, d_n=None):
     if residual is not None:
         y = y + residual
     return torch.relu(y) if relu else y
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dense 3x3 / stride 1 / pad 1 convolution of the BEV backbone on libspx's Winograd kernel (csrc/wino_conv2d.hip)
+
+_WINO_CACHE = {}
+
+
+def _wino_image(weight, flip):
+    """Transformed weight image; cached per (storage, version) when no gradient is being recorded (inference: the weights
+    do not change between calls), recomputed per call in training (they change every optimizer step; ~10 us)."""
+    if torch.is_grad_enabled() and weight.requires_grad:
+        return ops.wino_weight(weight, flip)
+    key = (weight.data_ptr(), tuple(weight.stride()), tuple(weight.shape), bool(flip))
+    hit = _WINO_CACHE.get(key)
+    if hit is not None and hit[0] == weight._version:
+        return hit[1]
+    u = ops.wino_weight(weight, flip)
+    if not torch.cuda.is_current_stream_capturing():
+        if len(_WINO_CACHE) > 256:
+            _WINO_CACHE.clear()
+        _WINO_CACHE[key] = (weight._version, u)
+    return u
+
+
+def wino_conv2d_ok(x, conv):
+    """nn.Conv2d `conv` over `x` is one spx_conv2d_wino call: 3x3, stride 1, padding 1, no bias / groups / dilation, fp32
+    channels-last map on the GPU, channel counts the kernel takes."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled()
+            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and conv.padding == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is None and conv.padding_mode == 'zeros'
+            and conv.weight.dtype == torch.float32 and ops.wino_ok(conv.in_channels, conv.out_channels)
+            and x.shape[1] == conv.in_channels and ops._cl_ld(x) is not None)
+
+
+class _WinoConv2dFn(torch.autograd.Function):
+    """y = conv2d(x, w, padding=1): forward and data gradient on the Winograd kernel (the data gradient is the same kernel
+    over dy with the rotated / transposed filter image); the weight gradient stays with the vendor library
+    (aten.convolution_backward with only the weight mask set)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return ops.conv2d_wino(x, _wino_image(weight, False), weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = None
+        if ops._cl_ld(dy) is None:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[0]:
+            if ops.wino_ok(weight.shape[0], weight.shape[1]):
+                dx = ops.conv2d_wino(dy, ops.wino_weight(weight, True), weight.shape[1])
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1]
+        return dx, dw
+
+
+def wino_conv2d(x, weight, scale=None, shift=None, relu=False):
+    """conv2d(x, weight, padding=1) on the Winograd kernel; scale / shift / relu: the folded inference epilogue
+    relu?(y * scale[c] + shift[c]) (no autograd through it)."""
+    if scale is not None or shift is not None or relu:
+        assert not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad))
+        return ops.conv2d_wino(x, _wino_image(weight, False), weight.shape[0], scale=scale, shift=shift, relu=relu)
+    return _WinoConv2dFn.apply(x, weight)

@@ -673,6 +673,65 @@ def bn_apply(x, mean, invstd, gamma, beta, relu, residual=None, out=None, d_n=No
     return y
 
 
+def wino_ok(cin, cout):
+    """Channel counts spx_conv2d_wino takes (else the caller keeps the vendor convolution)."""
+    return cin % 32 == 0 and cout % 128 == 0
+
+
+def wino_weight(weight, flip=False):
+    """Transformed weight image of a [Cout, Cin, 3, 3] filter (any strides) for conv2d_wino.  flip: the image of the DATA
+    GRADIENT's filter (taps rotated, channel roles swapped) — conv2d_wino(dy, wino_weight(w, flip=True)) = dx."""
+    _need_gpu(weight)
+    assert weight.dim() == 4 and weight.shape[2] == 3 and weight.shape[3] == 3 and weight.dtype == torch.float32
+    lib = _lib.load()
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    k_in, k_out = (cout, cin) if flip else (cin, cout)
+    u = torch.empty((lib.spx_wino_weight_floats(k_in, k_out),), dtype=torch.float32, device=weight.device)
+    so, si, sa, sb = weight.stride()
+    check(lib.spx_wino_weight(_ptr(weight), so, si, sa, sb, k_in, k_out, int(bool(flip)), _ptr(u), _stream(weight)),
+          "spx_wino_weight")
+    return u
+
+
+def conv2d_wino(x, u, cout, scale=None, shift=None, relu=False, out=None):
+    """3x3 / stride 1 / pad 1 convolution of a channels-last map.  x: [N, Cin, H, W] tensor in channels_last memory format
+    (or any [N, Cin, H, W] view whose pixels are dense rows: stride (H*W*ld, 1, W*ld, ld)); u: wino_weight image;
+    returns [N, cout, H, W] channels_last (or writes `out`, same layout rule).  Optional epilogue relu?(y*scale + shift)."""
+    _need_gpu(x, u)
+    lib = _lib.load()
+    n, cin, h, w = (int(v) for v in x.shape)
+    x_ld = _cl_ld(x)
+    if x_ld is None:
+        x = x.contiguous(memory_format=torch.channels_last)
+        x_ld = _cl_ld(x)
+    if out is None:
+        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    y_ld = _cl_ld(out)
+    if y_ld is None or tuple(out.shape) != (n, cout, h, w):
+        raise ValueError("out must be a float32 [N, Cout, H, W] channels-last map")
+    if u.numel() != lib.spx_wino_weight_floats(cin, cout):
+        raise ValueError("weight image does not match Cin=%d, Cout=%d" % (cin, cout))
+    check(lib.spx_conv2d_wino(_ptr(x), x_ld, _ptr(u), n, h, w, cin, cout, _ptr(scale), _ptr(shift), int(bool(relu)),
+                              _ptr(out), y_ld, _stream(x)), "spx_conv2d_wino")
+    return out
+
+
+def _cl_ld(t):
+    """Pixel pitch (floats) of a [N, C, H, W] float32 map whose memory is [N, H, W] rows of >= C channels, else None."""
+    if t.dtype != torch.float32 or t.dim() != 4:
+        return None
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    ld = sw if w > 1 else (sh if h > 1 else c)
+    if c > 1 and sc != 1:
+        return None
+    if ld < c or ld % 4 or t.data_ptr() % 16:
+        return None
+    if (w > 1 and sw != ld) or (h > 1 and sh != w * ld) or (n > 1 and sn != h * w * ld):
+        return None
+    return int(ld)
+
+
 def bn_relu_bwd(x, dy, gamma, beta, mean, invstd, relu, residual=None, d_n=None):
     """Backward of bn_relu_fwd; the ReLU mask is recomputed from x (and the residual) inside the kernels (y is not
     read).  dy may be a row view with its own stride (a channel slice of a wider gradient).  Returns dx, dgamma, dbeta
