@@ -44,8 +44,8 @@ def main():
         gf = 2.0 * 9 * c * c * n * h * w / 1e9
         err = float((out - F.conv2d(x, wt, padding=1)).abs().max())
         print("%dx%dx%dx%d: wino %.1f us (%.1f TF/s direct-equivalent, %.1f TF/s executed)  vendor %.1f us (%.1f TF/s)  "
-              "weight transform %.1f us  max|diff| %.2e" % (n, c, h, w, t_w, gf / t_w * 1e-3, gf / 2.25 / t_w * 1e-3, t_v,
-                                                             gf / t_v * 1e-3, t_u, err), flush=True)
+              "weight transform %.1f us  max|diff| %.2e" % (n, c, h, w, t_w, gf / t_w * 1e3, gf / 2.25 / t_w * 1e3, t_v,
+                                                             gf / t_v * 1e3, t_u, err), flush=True)
 
 
 if __name__ == "__main__":

@@ -28,15 +28,31 @@
 //     channels-last rows (512 contiguous bytes per pixel).
 #include "spx_common.h"
 
+#include <type_traits>
+
+// -DWINO_STAMP (dev builds of tools/hip/wino_probe.hip only): s_memtime stamps of one workgroup's waves 0 and 4
+#ifdef WINO_STAMP
+__device__ unsigned long long g_wino_stamps[2][64][16];
+#define WSTAMP(k)                                                                                       \
+  do {                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (stamp_slot >= 0 && lane == 0 && stamp_c < 64) g_wino_stamps[stamp_slot][stamp_c][k] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  } while (0)
+#else
+#define WSTAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTiles = 32;    // 2x2 output tiles per workgroup = MFMA rows
 constexpr int kKc = 8;        // input channels per K chunk
-constexpr int kSc = 32;       // input channels per super-chunk (4 chunks): one 128-byte line of a pixel
+constexpr int kSc = 16;       // input channels per super-chunk (2 chunks): one 64-byte half line of a pixel
 constexpr int kCoWg = 128;    // output channels per workgroup
 constexpr int kThreads = 512;
 constexpr int kPosFloats = kCoWg * kKc;   // floats of one (chunk, position) of the weight image
@@ -48,6 +64,7 @@ struct WinoArgs {
   const float* scale;  // [Cout] or null
   const float* shift;  // [Cout] or null
   int64_t x_ld, y_ld;
+  uint32_t x_bytes, u_bytes;   // extents of x and u for the buffer resources
   int32_t n, h, w, cin, cout;
   int32_t tiles_x, tiles_y;
   int64_t n_tiles;
@@ -66,10 +83,10 @@ __device__ __forceinline__ float dpp_q(float v) {   // lanes (0,1,2,3) of a quad
 }
 
 // Which input channel sits in k-slot `slot` (0..7) of chunk `chunk`.  A loader lane fetches 16 bytes (4 channels) per
-// pixel and 128-byte half; chunk kk of a super-chunk takes component kk of every such fetch, so the 8 k-slots of a chunk
-// are channels 32*S + 16*e + 4*g + kk  (g = slot >> 1: lane group, e = slot & 1: 64-byte half) — see the loader below.
+// pixel and super-chunk; chunk kk (0, 1) of the super-chunk takes components 2kk, 2kk+1 of every such fetch, so the 8
+// k-slots of a chunk are channels 16*S + 4*g + 2*kk + e  (g = slot >> 1: lane group, e = slot & 1) — see the loader below.
 __host__ __device__ constexpr int wino_channel(int chunk, int slot) {
-  return (chunk >> 2) * kSc + (slot & 1) * 16 + (slot >> 1) * 4 + (chunk & 3);
+  return (chunk >> 1) * kSc + (slot >> 1) * 4 + (chunk & 1) * 2 + (slot & 1);
 }
 
 // Transformed weight image u[cb][chunk][pos 16][nb 4][h 2][col 32][s 4]: cb = output-channel block of 128, nb = 32-column
@@ -139,16 +156,23 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
   const int nchunk = a.cin / kKc;
   const int nsuper = a.cin / kSc;
 
-  // ---- loader role (every thread): one patch column (4 pixels) of one tile, lane group g of 4.  Per super-chunk (32
-  // channels = one 128-byte line of each pixel) a thread fetches, for each of its 4 pixels, 16 bytes of the line's first
-  // half and 16 of its second (channels 4g..4g+3 and 16+4g..16+4g+3): the four lane groups of a pixel cover 64 contiguous
-  // bytes per instruction and every fetched line is used completely, once.  Component kk of the eight fetched vectors is
-  // the thread's share of chunk kk of the super-chunk (wino_channel), so one round of loads feeds four K chunks.
+  // ---- loader role (every thread): one patch column (4 pixels) of one tile, lane group g of 4.  Per super-chunk (16
+  // channels = a 64-byte half line of each pixel) a thread fetches 16 bytes (channels 4g..4g+3) of each of its 4 pixels:
+  // the four lane groups of a pixel cover the 64 contiguous bytes in one instruction.  Components 2kk, 2kk+1 of the four
+  // fetched vectors are the thread's share of chunk kk of the super-chunk (wino_channel), so one round of loads feeds two
+  // K chunks and every fetched byte is used.
   const int ld_col = tid & 3;           // patch column j — the 4 lanes of a DPP quad
   const int ld_g = (tid >> 2) & 3;      // lane group: channels 4g..4g+3 of each 64-byte half
   const int ld_tile = tid >> 4;         // tile inside the workgroup
-  const float* xrow[4];
-  float xmask[4];
+  // Both operands come in through buffer loads: a scalar resource + a 32-bit per-lane byte offset (+ a scalar offset for
+  // the weights) instead of 64-bit per-lane pointers, and an out-of-range offset reads as 0 — which IS the zero padding:
+  // pixels outside the map (and the tiles past the end) get offset 0xFFFFFFF0, no mask, no branch, same load count on
+  // every lane.  (host: both buffers < 4 GiB)
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_u =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, (int)a.u_bytes, 0x00020000);
+  uint32_t xoff[4];   // byte offset of the thread's 4 pixels (+ its lane group's 16 bytes)
   {
     const int64_t t = tile0 + ld_tile;
     const bool tv = t < a.n_tiles;
@@ -161,11 +185,8 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int py = 2 * ty - 1 + i;
       const bool ok = tv && px >= 0 && px < a.w && py >= 0 && py < a.h;
-      // out-of-map pixels (the zero padding) read pixel 0 and are multiplied by 0: every lane issues every load, so the
-      // number of loads in flight is the same on all paths and the compiler can wait for exactly the ones it needs
-      const int64_t pix = ok ? ((int64_t)nn * a.h + py) * a.w + px : 0;
-      xmask[i] = ok ? 1.0f : 0.0f;
-      xrow[i] = a.x + pix * a.x_ld + ld_g * 4;
+      const int64_t pix = ((int64_t)nn * a.h + py) * a.w + px;
+      xoff[i] = ok ? (uint32_t)((pix * a.x_ld + ld_g * 4) * 4) : 0xFFFFFFF0u;
     }
   }
   const float sgn = (ld_col == 1) ? 1.0f : -1.0f;
@@ -173,7 +194,9 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
 
   // ---- MFMA role
   // weights of this wave: positions 4*wrow .. +3, column blocks 2*half, 2*half+1 of block cb
-  const float* const ubase = a.u + (((int64_t)cb * nchunk * 16 + wrow * 4) * 4 + half * 2) * 256 + lane * 4;
+  const uint32_t u_wave = (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)(((((int64_t)cb * nchunk * 16 + wrow * 4) * 4 + half * 2) * 256) * 4));   // bytes, wave-uniform
+  const uint32_t u_lane = (uint32_t)lane * 16u;
   const float* const asrc = smem + (wrow * 4 * kTiles + l31) * kKc + lh * 4;
 
   f32x16 acc[4][2];
@@ -184,20 +207,18 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][nb][r] = 0.f;
 
-  f32x4 xr[4][2];   // [patch row][64-byte half]
+  f32x4 xr[4];   // [patch row]
   auto load_x = [&](int sc) {
     sc = sc < nsuper ? sc : nsuper - 1;   // past the end: repeat the last one (loaded, never used)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      xr[i][0] = *reinterpret_cast<const f32x4*>(xrow[i] + sc * kSc);
-      xr[i][1] = *reinterpret_cast<const f32x4*>(xrow[i] + sc * kSc + 16);
-    }
+    for (int i = 0; i < 4; ++i)
+      xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff[i], sc * (kSc * 4), 0));
   };
   // transforms chunk kk of the super-chunk in xr into V buffer `buf`
   auto transform_store = [&](int buf, int kk) {
     f32x2 d[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) d[i] = f32x2{xr[i][0][kk], xr[i][1][kk]} * xmask[i];
+    for (int i = 0; i < 4; ++i) d[i] = f32x2{xr[i][2 * kk], xr[i][2 * kk + 1]};
     // column pass (over patch rows): t = B^T d
     f32x2 t[4];
     t[0] = d[0] - d[2];
@@ -220,27 +241,37 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
   f32x4 bw[4][2];
   auto load_b = [&](int chunk, int j) {
     chunk = chunk < nchunk ? chunk : nchunk - 1;   // the last chunk re-reads itself: constant load count per iteration
-    const float* p = ubase + (int64_t)chunk * 16 * kPosFloats + j * kPosFloats;
-    bw[j][0] = *reinterpret_cast<const f32x4*>(p);
-    bw[j][1] = *reinterpret_cast<const f32x4*>(p + 256);
+    const int so = (int)u_wave + (chunk * 16 + j) * (kPosFloats * 4);
+    bw[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)u_lane, so, 0));
+    bw[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)u_lane, so + 1024, 0));
   };
+#ifdef WINO_STAMP
+  const int stamp_slot = (blockIdx.x == 30 && blockIdx.y == 0) ? (wave == 0 ? 0 : wave == 4 ? 1 : -1) : -1;
+  int stamp_c = 0;
+#endif
   auto mma = [&](int buf, int next_chunk) {
     const float* s = asrc + buf * (16 * kTiles * kKc);
-    f32x4 av[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(s + j * (kTiles * kKc));
-    __builtin_amdgcn_sched_barrier(0);
+    f32x4 av = *reinterpret_cast<const f32x4*>(s);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      f32x4 an = av;
+      if (j < 3) an = *reinterpret_cast<const f32x4*>(s + (j + 1) * (kTiles * kKc));   // next position's A fragment
+      WSTAMP(2 + 3 * j);
 #pragma unroll
       for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-          acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][st], bw[j][nb][st], acc[j][nb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) {
+          acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bw[j][nb][st], acc[j][nb], 0, 0, 0);
+#ifdef WINO_STAMP
+          if (st == 0 && nb == 0) WSTAMP(3 + 3 * j);
+#endif
+        }
       load_b(next_chunk, j);
+      WSTAMP(4 + 3 * j);
       // keep the re-load HERE: left alone, the scheduler sinks all eight loads below the last MFMA of the chunk and the
       // next chunk then starts by waiting out their L2 latency
       __builtin_amdgcn_sched_barrier(0);
+      av = an;
     }
   };
 
@@ -254,18 +285,44 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
 
   // One barrier per chunk: iteration c multiplies chunk c out of buffer c&1 while chunk c+1 is transformed into the other
   // buffer (last read in iteration c-1, i.e. before the barrier that ended it).  The x registers of super-chunk S are
-  // dead after chunk 4S+3 has been transformed (iteration 4S+2); super-chunk S+1 is fetched right there and first used
-  // one iteration later.  The transform after the last chunk rewrites a buffer nobody reads again.
-  for (int sc = 0; sc < nsuper; ++sc) {
+  // dead after chunk 2S+1 has been transformed (iteration 2S); super-chunk S+1 is fetched right there and first used one
+  // iteration later.  The transform after the last chunk rewrites a buffer nobody reads again.
+  // The two waves of a SIMD take the transform at opposite ends of the iteration — waves 0..3 before their MFMAs, waves
+  // 4..7 after — so that one of them always has MFMAs to issue: done by both at the top, the matrix pipe sat idle for the
+  // length of a transform in every chunk.  Two copies of the loop (not a branch inside one) keep the count of loads in
+  // flight known on each path.
+  auto k_loop = [&](auto early_tag) {
+    constexpr bool kEarly = decltype(early_tag)::value;
+    for (int sc = 0; sc < nsuper; ++sc) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int c = sc * 4 + kk;
-      transform_store((kk & 1) ^ 1, (kk + 1) & 3);
-      if (kk == 2) load_x(sc + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(kk & 1, c + 1);
-      __syncthreads();
+      for (int kk = 0; kk < 2; ++kk) {
+        const int c = sc * 2 + kk;
+#ifdef WINO_STAMP
+        stamp_c = c;
+#endif
+        WSTAMP(0);
+        if (kEarly) {
+          transform_store(kk ^ 1, kk ^ 1);
+          if (kk == 0) load_x(sc + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        WSTAMP(1);
+        mma(kk, c + 1);
+        if (!kEarly) {
+          __builtin_amdgcn_sched_barrier(0);
+          transform_store(kk ^ 1, kk ^ 1);
+          if (kk == 0) load_x(sc + 1);
+        }
+        WSTAMP(14);
+        __syncthreads();
+        WSTAMP(15);
+      }
     }
+  };
+  if (__builtin_amdgcn_readfirstlane(half) == 0) {
+    k_loop(std::true_type{});
+  } else {
+    k_loop(std::false_type{});
   }
 
   // ---- output transform.  This wave holds M[i = wrow][j = 0..3]; (M A)[i][0] = M0 + M1 + M2, (M A)[i][1] = M1 - M2 - M3;
@@ -343,9 +400,12 @@ extern "C" int spx_conv2d_wino(const float* x, int64_t x_ld, const float* u, int
                                spx_stream_t stream) {
   if (n <= 0 || h <= 0 || w <= 0) return SPX_OK;
   if (cin % kSc != 0 || cout % kCoWg != 0 || x_ld < cin || y_ld < cout || (x_ld & 3) || (y_ld & 3)) return SPX_ERR_INVALID_ARG;
+  const int64_t x_bytes = ((int64_t)n * h * w - 1) * x_ld * 4 + (int64_t)cin * 4, u_bytes = (int64_t)16 * cin * cout * 4;
+  if (x_bytes >= 0xFFFFFFF0ll || u_bytes >= 0x7FFFFFFFll) return SPX_ERR_TOO_LARGE;
   WinoArgs a;
   a.x = x; a.u = u; a.y = y; a.scale = scale; a.shift = shift;
   a.x_ld = x_ld; a.y_ld = y_ld;
+  a.x_bytes = (uint32_t)x_bytes; a.u_bytes = (uint32_t)u_bytes;
   a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
   a.tiles_x = (w + 1) / 2; a.tiles_y = (h + 1) / 2;
   a.n_tiles = (int64_t)n * a.tiles_x * a.tiles_y;
