@@ -143,34 +143,44 @@ def _bev(train):
 
 @pytest.mark.parametrize("train", [False, True])
 def test_bev_backbone_with_and_without_winograd(train):
-    """BaseBEVBackbone forward (and, training, every parameter gradient) with the Winograd rewrite on and off."""
+    """BaseBEVBackbone forward (and, training, every parameter gradient) with the Winograd rewrite on and off, both against
+    the same modules run in float64 on the CPU.  Train-mode BatchNorm over these small maps makes the weight gradients of
+    the convolutions before it differences of nearly cancelling terms, so fp32 round-off anywhere upstream is amplified:
+    the bar for the Winograd path is the error the vendor path itself shows against float64 (x4, floor 1e-4)."""
+    import copy
     import pcdet_amd.models.backbones_2d.base_bev_backbone as bb
     m = _bev(train)
     x = torch.randn((2, 64, 24, 20), generator=torch.Generator().manual_seed(4)).cuda().contiguous(memory_format=torch.channels_last)
-    outs, grads = [], []
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def run(model, inp, wt):
+        for p in model.parameters():
+            p.grad = None
+        if train:
+            y = model({'spatial_features': inp})['spatial_features_2d']
+            (y * wt.to(y.dtype).to(y.device).view_as(y)).sum().backward()
+            return y.detach().double().cpu(), [p.grad.detach().double().cpu() for p in model.parameters()]
+        with torch.no_grad():
+            y = model({'spatial_features': inp})['spatial_features_2d']
+        return y.double().cpu(), []
+
+    m64 = copy.deepcopy(m).double().cpu().train(train)
+    wt = None
+    with torch.no_grad():
+        wt = torch.linspace(0.5, 1.5, 2 * 512 * 24 * 20, dtype=torch.float64)
+    y_ref, g_ref = run(m64, x.double().cpu(), wt)
+    errs = {}
     for flag in (False, True):
         bb._WINO = flag
         try:
-            for p in m.parameters():
-                p.grad = None
-            if train:
-                # identical running statistics for both passes
-                state = {k: v.clone() for k, v in m.state_dict().items()}
-                y = m({'spatial_features': x})['spatial_features_2d']
-                (y * torch.linspace(0.5, 1.5, y.numel(), device='cuda').view_as(y)).sum().backward()
-                grads.append([p.grad.clone() for p in m.parameters()])
-                m.load_state_dict(state)
-            else:
-                with torch.no_grad():
-                    y = m({'spatial_features': x})['spatial_features_2d']
-            outs.append(y.detach().clone())
+            m.load_state_dict(state)
+            y, g = run(m, x, wt)
         finally:
             bb._WINO = True
-    scale = float(outs[0].abs().max())
-    assert float((outs[0] - outs[1]).abs().max()) <= 1e-4 * scale
-    if train:
-        # train-mode BatchNorm makes every conv's weight gradient a difference of large, nearly cancelling terms, so fp32
-        # re-association upstream shows amplified here (same bar as the static-vs-dynamic train-step test)
-        worst = max(float((a - b).abs().max()) / max(1e-3, float(a.abs().max())) for a, b in zip(*grads))
-        print("worst relative parameter-gradient difference %.2e" % worst)
-        assert worst <= 2e-2
+        e_y = float((y - y_ref).abs().max() / y_ref.abs().max())
+        e_g = max([float((a - b).abs().max() / b.abs().max().clamp_min(1e-3)) for a, b in zip(g, g_ref)] or [0.0])
+        errs[flag] = (e_y, e_g)
+    print("vs float64: vendor path output %.2e grads %.2e | winograd path output %.2e grads %.2e"
+          % (errs[False] + errs[True]))
+    assert errs[True][0] <= max(4 * errs[False][0], 1e-5)
+    assert errs[True][1] <= max(4 * errs[False][1], 1e-4)

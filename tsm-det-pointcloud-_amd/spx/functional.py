@@ -335,23 +335,19 @@ def bn_act(x, bn, relu, residual=None, d_n=None):
 # ---------------------------------------------------------------------------------------------------------------------
 # dense 3x3 / stride 1 / pad 1 convolution of the BEV backbone on libspx's Winograd kernel (csrc/wino_conv2d.hip)
 
-_WINO_CACHE = {}
-
-
 def _wino_image(weight, flip):
-    """Transformed weight image; cached per (storage, version) when no gradient is being recorded (inference: the weights
-    do not change between calls), recomputed per call in training (they change every optimizer step; ~10 us)."""
+    """Transformed weight image; kept ON the weight tensor (attribute, with the version it was made from) when no gradient
+    is being recorded — inference: the weights do not change between calls —, recomputed per call in training (they
+    change every optimizer step; ~10 us)."""
     if torch.is_grad_enabled() and weight.requires_grad:
         return ops.wino_weight(weight, flip)
-    key = (weight.data_ptr(), tuple(weight.stride()), tuple(weight.shape), bool(flip))
-    hit = _WINO_CACHE.get(key)
-    if hit is not None and hit[0] == weight._version:
-        return hit[1]
+    attr = '_spx_wino_flip' if flip else '_spx_wino'
+    hit = getattr(weight, attr, None)
+    if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr() and hit[2].device == weight.device:
+        return hit[2]
     u = ops.wino_weight(weight, flip)
     if not torch.cuda.is_current_stream_capturing():
-        if len(_WINO_CACHE) > 256:
-            _WINO_CACHE.clear()
-        _WINO_CACHE[key] = (weight._version, u)
+        setattr(weight, attr, (weight._version, weight.data_ptr(), u))
     return u
 
 
