@@ -379,6 +379,16 @@ int spx_wino_weight(const float *w, int64_t s_o, int64_t s_i, int64_t s_a, int64
 int spx_conv2d_wino(const float *x, int64_t x_ld, const float *u, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
                     const float *scale, const float *shift, int relu, float *y, int64_t y_ld, spx_stream_t stream);
 
+/* spx_conv2d_wino_wgrad: weight gradient of the same convolution in the Winograd domain (csrc/wino_wgrad.hip):
+ *    dw[co*s_o + ci*s_i + a*s_a + b*s_b] = sum over pixels of x[.., ci] (shifted by the tap) * dy[.., co]  — the weight half
+ *    of convolution_backward for the layers of 9b.  cin % 128 == 0 and cout % 128 == 0 (else SPX_ERR_INVALID_ARG), map at
+ *    least 15 pixels wide (else SPX_ERR_UNSUPPORTED: callers keep the vendor kernel).  ws: spx_wino_wgrad_ws_bytes bytes
+ *    (per-split partial sums, summed in a fixed order: deterministic, no atomics). */
+size_t spx_wino_wgrad_ws_bytes(int32_t cin, int32_t cout);
+int spx_conv2d_wino_wgrad(const float *x, int64_t x_ld, const float *dy, int64_t dy_ld, int32_t n, int32_t h, int32_t w,
+                          int32_t cin, int32_t cout, float *dw, int64_t s_o, int64_t s_i, int64_t s_a, int64_t s_b, void *ws,
+                          size_t ws_bytes, spx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 10. Voxel query (consumers of multi_scale_3d_features)
  *    replaces: pointnet2_stack_cuda.voxel_query_wrapper, reference

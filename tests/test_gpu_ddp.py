@@ -81,8 +81,17 @@ def test_ddp_two_ranks_on_the_hip_path(tmp_path, static):
         ret, _tb, _ = model(_batch(ds, fid, dev, static, model))
         ret["loss"].backward()
         singles.append({n: p.grad.detach().cpu() for n, p in model.named_parameters()})
-    worst = 0.0
+    # Measured over ALL gradients at once (relative L2).  Not per element: the two processes share the GPU, the vendor's
+    # atomic split-K kernels then add in another order than in the single-process runs, and with ~1e6 ReLU inputs per step
+    # some element always sits within that round-off of the kink at 0 — when it flips, the gradient of its whole channel
+    # moves by ~10 % (seen: 1e-7 typical, 2.5e-4 and 0.11 per-element on single parameters).  What this test is about —
+    # averaging over ranks, frames sharded, the same kernels under DDP — moves the global figure by 0.3 or more.
+    num = den = 0.0
+    errs = []
     for n in singles[0]:
         want = 0.5 * (singles[0][n] + singles[1][n])
-        worst = max(worst, float((r0["grads"][n] - want).abs().max() / want.abs().max().clamp_min(1e-12)))
-    assert worst < 1e-5, worst
+        num += float(((r0["grads"][n] - want).double() ** 2).sum())
+        den += float((want.double() ** 2).sum())
+        errs.append((float((r0["grads"][n] - want).abs().max() / want.abs().max().clamp_min(1e-12)), n))
+    errs.sort(reverse=True)
+    assert (num / den) ** 0.5 < 2e-2, ((num / den) ** 0.5, errs[:6])

@@ -106,6 +106,43 @@ def test_rejects_unsupported_channels():
         ops.wino_weight(wt)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(1, 16, 16, 128, 128), (2, 15, 19, 128, 128), (3, 33, 17, 128, 256),
+                                             (1, 26, 22, 256, 128), (2, 9, 30, 256, 256)])
+def test_weight_gradient_matches_float64(n, h, w, cin, cout):
+    """Winograd-domain weight gradient (csrc/wino_wgrad.hip) against conv2d autograd in float64; the vendor's fp32 weight
+    gradient is measured against the same reference beside it."""
+    from spx import ops
+    g = torch.Generator().manual_seed(n * 100 + h + w)
+    x = torch.randn((n, cin, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((n, cout, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    wt = torch.zeros((cout, cin, 3, 3), device="cuda")
+    dw = ops.conv2d_wino_wgrad(x, dy, wt)
+    wr = torch.zeros((cout, cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().cpu(), wr, padding=1).backward(dy.double().cpu())
+    e_w = _check(dw, wr.grad.detach())
+    dv = torch.ops.aten.convolution_backward(dy, x, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+    e_v = _check(dv, wr.grad.detach(), tol=1e-4)
+    print("rel err wino wgrad %.2e  vendor wgrad %.2e" % (e_w, e_v))
+    # twice the same bits (fixed summation order, no atomics)
+    assert torch.equal(dw, ops.conv2d_wino_wgrad(x, dy, wt))
+
+
+def test_weight_gradient_channels_last_weight_and_slices():
+    from spx import ops
+    g = torch.Generator().manual_seed(77)
+    big = torch.randn((2, 384, 12, 20), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    x = big[:, 128:256]
+    dyb = torch.randn((2, 256, 12, 20), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    dy = dyb[:, 128:]
+    like = torch.zeros((128, 128, 3, 3), device="cuda").contiguous(memory_format=torch.channels_last)
+    dw = ops.conv2d_wino_wgrad(x, dy, like)
+    assert dw.stride() == like.stride()
+    wr = torch.zeros((128, 128, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().cpu(), wr, padding=1).backward(dy.double().cpu())
+    _check(dw, wr.grad.detach())
+    assert not ops.wino_wgrad_ok(128, 128, 13) and ops.wino_wgrad_ok(128, 128, 15) and not ops.wino_wgrad_ok(64, 128, 100)
+
+
 def test_autograd_matches_vendor_conv():
     """_WinoConv2dFn: output, data gradient (Winograd kernel with the flipped image) and weight gradient (vendor wrw)
     against torch's conv2d autograd in float64."""
@@ -136,8 +173,11 @@ def _bev(train):
         if isinstance(mod, torch.nn.BatchNorm2d):
             mod.running_mean.normal_(0, 0.1)
             mod.running_var.uniform_(0.5, 1.5)
-            mod.weight.data.uniform_(0.5, 1.5)
-            mod.bias.data.normal_(0, 0.1)
+            # pre-activations well away from 0: the ReLU that follows has a kink there, and an element within fp32 round-off
+            # of it makes the gradient of a whole channel jump (seen: one element at 7e-7 flipping between two runs of the
+            # SAME path) — nothing to do with which convolution kernel ran
+            mod.weight.data.uniform_(0.1, 0.3)
+            mod.bias.data.normal_(2.5, 0.1)
     return m.train(train)
 
 
@@ -178,9 +218,30 @@ def test_bev_backbone_with_and_without_winograd(train):
         finally:
             bb._WINO = True
         e_y = float((y - y_ref).abs().max() / y_ref.abs().max())
-        e_g = max([float((a - b).abs().max() / b.abs().max().clamp_min(1e-3)) for a, b in zip(g, g_ref)] or [0.0])
+        per = [float((a - b).abs().max() / b.abs().max().clamp_min(1e-3)) for a, b in zip(g, g_ref)]
+        e_g = max(per or [0.0])
+        if per:
+            names = [k for k, _ in m.named_parameters()]
+            print("winograd=%s worst parameter gradients:" % flag,
+                  sorted(zip(per, names, [tuple(p.shape) for p in m.parameters()]), reverse=True)[:4])
         errs[flag] = (e_y, e_g)
     print("vs float64: vendor path output %.2e grads %.2e | winograd path output %.2e grads %.2e"
           % (errs[False] + errs[True]))
     assert errs[True][0] <= max(4 * errs[False][0], 1e-5)
     assert errs[True][1] <= max(4 * errs[False][1], 1e-4)
+
+
+def test_autograd_rectangular_channels_fall_back_per_direction():
+    """64 -> 128 channels: forward on the Winograd kernel (Cin % 16, Cout % 128), data gradient (needs Cin % 128) and weight
+    gradient (needs both % 128) through the vendor library — every direction still matches float64."""
+    from spx.functional import wino_conv2d
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn((2, 64, 10, 16), generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn((128, 64, 3, 3), generator=g) / 24).cuda().requires_grad_(True)
+    dy = torch.randn((2, 128, 10, 16), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    wino_conv2d(x, w).backward(dy)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    wr = w.detach().double().cpu().requires_grad_(True)
+    F.conv2d(xr, wr, padding=1).backward(dy.double().cpu())
+    _check(x.grad, xr.grad)
+    _check(w.grad, wr.grad, tol=5e-5)

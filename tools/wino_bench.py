@@ -41,11 +41,17 @@ def main():
         t_w = timeit(lambda: ops.conv2d_wino(x, u, c, out=out), args.iters)
         t_v = timeit(lambda: F.conv2d(x, wt, padding=1), args.iters)
         t_u = timeit(lambda: ops.wino_weight(wt), args.iters)
+        dy = torch.randn_like(x)
+        t_gw = timeit(lambda: ops.conv2d_wino_wgrad(x, dy, wt), args.iters)
+        t_gv = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, wt, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                                   (False, True, False)), args.iters)
         gf = 2.0 * 9 * c * c * n * h * w / 1e9
         err = float((out - F.conv2d(x, wt, padding=1)).abs().max())
         print("%dx%dx%dx%d: wino %.1f us (%.1f TF/s direct-equivalent, %.1f TF/s executed)  vendor %.1f us (%.1f TF/s)  "
               "weight transform %.1f us  max|diff| %.2e" % (n, c, h, w, t_w, gf / t_w * 1e3, gf / 2.25 / t_w * 1e3, t_v,
                                                              gf / t_v * 1e3, t_u, err), flush=True)
+        print("      weight gradient: wino %.1f us (%.1f TF/s direct-equivalent)  vendor %.1f us (%.1f TF/s)"
+              % (t_gw, gf / t_gw * 1e3, t_gv, gf / t_gv * 1e3), flush=True)
 
 
 if __name__ == "__main__":

@@ -76,6 +76,9 @@ SIGNATURES = {
     "spx_wino_weight_floats": (_i64, [_int, _int]),
     "spx_wino_weight": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "spx_conv2d_wino": (_int, [_vp, _i64, _vp, _int, _int, _int, _int, _int, _vp, _vp, _int, _vp, _i64, _vp]),
+    "spx_wino_wgrad_ws_bytes": (_sz, [_int, _int]),
+    "spx_conv2d_wino_wgrad": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _int, _int, _vp, _i64, _i64, _i64, _i64, _vp, _sz,
+                                     _vp]),
     "spx_anchor_loss_ws_bytes": (_sz, [_int, _i64]),
     "spx_anchor_loss": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _int, _int, ctypes.c_float, ctypes.c_float,
                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _sz,

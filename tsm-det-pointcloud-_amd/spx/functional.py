@@ -3,6 +3,8 @@
 Replaces the autograd behaviour of spconv.pytorch convolutions / .dense() that the reference triggers with
 loss.backward() (tools/train_utils/train_utils.py:53).
 """
+import os
+
 import torch
 
 from . import ops
@@ -336,19 +338,25 @@ def bn_act(x, bn, relu, residual=None, d_n=None):
 # dense 3x3 / stride 1 / pad 1 convolution of the BEV backbone on libspx's Winograd kernel (csrc/wino_conv2d.hip)
 
 def _wino_image(weight, flip):
-    """Transformed weight image; kept ON the weight tensor (attribute, with the version it was made from) when no gradient
-    is being recorded — inference: the weights do not change between calls —, recomputed per call in training (they
-    change every optimizer step; ~10 us)."""
-    if torch.is_grad_enabled() and weight.requires_grad:
-        return ops.wino_weight(weight, flip)
+    """Transformed weight image of `weight` (flip: of its data-gradient filter), in a buffer that lives ON the weight tensor
+    (attribute) and is re-filled when the weight has changed: once per call in training (the optimizer steps in between;
+    ~10 us), once in all at inference.  One persistent buffer per layer and direction — no allocation per call."""
     attr = '_spx_wino_flip' if flip else '_spx_wino'
     hit = getattr(weight, attr, None)
-    if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr() and hit[2].device == weight.device:
+    fresh = hit is not None and hit[1] == weight.data_ptr() and hit[2].device == weight.device
+    if fresh and hit[0] == weight._version and not (torch.is_grad_enabled() and weight.requires_grad):
         return hit[2]
-    u = ops.wino_weight(weight, flip)
-    if not torch.cuda.is_current_stream_capturing():
-        setattr(weight, attr, (weight._version, weight.data_ptr(), u))
+    if torch.cuda.is_current_stream_capturing():
+        return ops.wino_weight(weight, flip)            # a captured graph owns its buffers
+    u = ops.wino_weight(weight, flip, out=hit[2] if fresh else None)
+    setattr(weight, attr, (weight._version, weight.data_ptr(), u))
     return u
+
+
+def _wino_image_always(weight, flip):
+    """Backward runs with grad mode off; the image must still follow the weight of THIS step."""
+    with torch.enable_grad():
+        return _wino_image(weight, flip)
 
 
 def wino_conv2d_ok(x, conv):
@@ -361,10 +369,13 @@ def wino_conv2d_ok(x, conv):
             and x.shape[1] == conv.in_channels and ops._cl_ld(x) is not None)
 
 
+_WINO_WGRAD = os.environ.get("SPX_BEV_WINOGRAD_WGRAD", "1") != "0"      # dev knob
+
+
 class _WinoConv2dFn(torch.autograd.Function):
-    """y = conv2d(x, w, padding=1): forward and data gradient on the Winograd kernel (the data gradient is the same kernel
-    over dy with the rotated / transposed filter image); the weight gradient stays with the vendor library
-    (aten.convolution_backward with only the weight mask set)."""
+    """y = conv2d(x, w, padding=1): forward, data gradient (the same kernel over dy with the rotated / transposed filter
+    image) and weight gradient (csrc/wino_wgrad.hip) in the Winograd domain; shapes the weight-gradient kernel does not
+    take go to the vendor library (aten.convolution_backward with only the weight mask set)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -379,13 +390,16 @@ class _WinoConv2dFn(torch.autograd.Function):
             dy = dy.contiguous(memory_format=torch.channels_last)
         if ctx.needs_input_grad[0]:
             if ops.wino_ok(weight.shape[0], weight.shape[1]):
-                dx = ops.conv2d_wino(dy, ops.wino_weight(weight, True), weight.shape[1])
+                dx = ops.conv2d_wino(dy, _wino_image_always(weight, True), weight.shape[1])
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                          (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                     (False, True, False))[1]
+            if _WINO_WGRAD and ops.wino_wgrad_ok(weight.shape[1], weight.shape[0], x.shape[3]):
+                dw = ops.conv2d_wino_wgrad(x, dy, weight)
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (False, True, False))[1]
         return dx, dw
 
 

@@ -678,15 +678,20 @@ def wino_ok(cin, cout):
     return cin % 32 == 0 and cout % 128 == 0
 
 
-def wino_weight(weight, flip=False):
+def wino_weight(weight, flip=False, out=None):
     """Transformed weight image of a [Cout, Cin, 3, 3] filter (any strides) for conv2d_wino.  flip: the image of the DATA
-    GRADIENT's filter (taps rotated, channel roles swapped) — conv2d_wino(dy, wino_weight(w, flip=True)) = dx."""
+    GRADIENT's filter (taps rotated, channel roles swapped) — conv2d_wino(dy, wino_weight(w, flip=True)) = dx.
+    out: a buffer of a previous call for the same shape to refill instead of allocating."""
     _need_gpu(weight)
     assert weight.dim() == 4 and weight.shape[2] == 3 and weight.shape[3] == 3 and weight.dtype == torch.float32
     lib = _lib.load()
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
     k_in, k_out = (cout, cin) if flip else (cin, cout)
-    u = torch.empty((lib.spx_wino_weight_floats(k_in, k_out),), dtype=torch.float32, device=weight.device)
+    nfl = lib.spx_wino_weight_floats(k_in, k_out)
+    if out is not None and out.numel() == nfl and out.device == weight.device and out.dtype == torch.float32:
+        u = out
+    else:
+        u = torch.empty((nfl,), dtype=torch.float32, device=weight.device)
     so, si, sa, sb = weight.stride()
     check(lib.spx_wino_weight(_ptr(weight), so, si, sa, sb, k_in, k_out, int(bool(flip)), _ptr(u), _stream(weight)),
           "spx_wino_weight")
@@ -714,6 +719,35 @@ def conv2d_wino(x, u, cout, scale=None, shift=None, relu=False, out=None):
     check(lib.spx_conv2d_wino(_ptr(x), x_ld, _ptr(u), n, h, w, cin, cout, _ptr(scale), _ptr(shift), int(bool(relu)),
                               _ptr(out), y_ld, _stream(x)), "spx_conv2d_wino")
     return out
+
+
+def wino_wgrad_ok(cin, cout, w):
+    """Shapes spx_conv2d_wino_wgrad takes (else the caller keeps the vendor weight-gradient kernel)."""
+    return cin % 128 == 0 and cout % 128 == 0 and (w + 1) // 2 >= 8
+
+
+def conv2d_wino_wgrad(x, dy, like):
+    """Weight gradient of conv2d(x, w, padding=1) for a [Cout, Cin, 3, 3] weight, written with the strides of `like`.
+    x [N, Cin, H, W], dy [N, Cout, H, W]: channels-last maps (see conv2d_wino)."""
+    _need_gpu(x, dy)
+    lib = _lib.load()
+    n, cin, h, w = (int(v) for v in x.shape)
+    cout = int(dy.shape[1])
+    x_ld, dy_ld = _cl_ld(x), _cl_ld(dy)
+    if x_ld is None:
+        x = x.contiguous(memory_format=torch.channels_last)
+        x_ld = _cl_ld(x)
+    if dy_ld is None:
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dy_ld = _cl_ld(dy)
+    assert tuple(like.shape) == (cout, cin, 3, 3) and tuple(dy.shape) == (n, cout, h, w)
+    dw = torch.empty_like(like)
+    so, si, sa, sb = dw.stride()
+    wsb = lib.spx_wino_wgrad_ws_bytes(cin, cout)
+    ws = workspace(x.device, wsb)
+    check(lib.spx_conv2d_wino_wgrad(_ptr(x), x_ld, _ptr(dy), dy_ld, n, h, w, cin, cout, _ptr(dw), so, si, sa, sb, _ptr(ws), wsb,
+                                    _stream(x)), "spx_conv2d_wino_wgrad")
+    return dw
 
 
 def _cl_ld(t):
