@@ -186,7 +186,7 @@ class KernelTimer(object):
         from spx import ops
         t = self
         names = ["conv_gemm", "conv_gemm_balanced", "conv_plan", "conv_group", "conv_wgrad", "subm_rulebook", "conv_rulebook", "voxelize",
-                 "densify", "densify_bwd", "pack_weight"]
+                 "densify", "densify_bwd", "pack_weight", "conv2d_wino", "conv2d_wino_wgrad", "wino_weight"]
         self._saved = {n: getattr(ops, n) for n in names}
         sv = self._saved
 
@@ -268,6 +268,35 @@ class KernelTimer(object):
         def pack_weight(weight, mode):
             return t._timed("pack_weight", 0.0, 8.0 * weight.numel(), sv["pack_weight"], weight, mode)
 
+        def conv2d_wino(x, u, cout, scale=None, shift=None, relu=False, out=None):
+            # dense 3x3 conv of the BEV backbone, Winograd F(2x2, 3x3): the kernel EXECUTES 16 multiply-adds per 2x2 output tile
+            # and (ci, co) — 4 per output pixel — where the direct form has 9; `flops` is what runs on the MFMA, the
+            # direct-form figure is 2.25x that (reported beside it).  bytes: map in + map out + the weight image.
+            n, cin, h, w = x.shape
+            tiles = n * ((h + 1) // 2) * ((w + 1) // 2)
+            flops = 2.0 * 16 * tiles * cin * cout
+            nbytes = 4.0 * (n * h * w * (cin + cout) + 16 * cin * cout)
+            # the family name carries the launch size (threads) so that the PMC rows of tools/pmc_traffic.sh match it
+            grid = ((tiles + 31) // 32) * (cout // 128) * 512
+            return t._timed("conv2d_wino[%d->%d @%d]" % (cin, cout, grid), flops, nbytes, sv["conv2d_wino"], x, u, cout, scale,
+                            shift, relu, out)
+
+        def conv2d_wino_wgrad(x, dy, like):
+            n, cin, h, w = x.shape
+            cout = dy.shape[1]
+            tiles = n * ((h + 1) // 2) * ((w + 1) // 2)
+            flops = 2.0 * 16 * tiles * cin * cout
+            nbytes = 4.0 * (n * h * w * (cin + cout) + 9 * cin * cout)
+            ns = max(8, (64 // ((cin // 128) * (cout // 128))) & ~7)          # csrc/wino_wgrad.hip: wgrad_splits
+            grid = 4 * ns * (cin // 128) * (cout // 128) * 512
+            return t._timed("conv2d_wino_wgrad[%dx%d @%d]" % (cin, cout, grid), flops, nbytes, sv["conv2d_wino_wgrad"], x, dy,
+                            like)
+
+        def wino_weight(weight, flip=False, out=None):
+            return t._timed("wino_weight", 0.0, 4.0 * weight.numel() * (1 + 16.0 / 9), sv["wino_weight"], weight, flip, out)
+
+        for n, f in dict(conv2d_wino=conv2d_wino, conv2d_wino_wgrad=conv2d_wino_wgrad, wino_weight=wino_weight).items():
+            setattr(ops, n, f)
         for n, f in dict(conv_gemm=conv_gemm, conv_gemm_balanced=conv_gemm_balanced, conv_plan=conv_plan,
                          conv_group=conv_group, conv_wgrad=conv_wgrad, subm_rulebook=subm_rulebook,
                          conv_rulebook=conv_rulebook, voxelize=voxelize, densify=densify, densify_bwd=densify_bwd,
@@ -332,6 +361,15 @@ def roofline_of(fam):
             return 4 if m == 3 else (8 if m > 4 else m)
         ci, co = name[len("conv_wgrad[mfma "):-1].split("x")
         rocprof_name = "k_wgrad_mfma<%d, %d," % (_t(ci), _t(co))       # one API call = + k_wgrad_count + k_wgrad_reduce
+    extra = {}
+    if name.startswith("conv2d_wino["):
+        rocprof_name = "k_wino_conv@" + name.split("@")[1].rstrip("]")
+        extra = {"flops_counted": "executed (Winograd domain: 16 multiply-adds per 2x2 tile and channel pair)",
+                 "direct_form_equivalent_TFLOP_s": round(2.25 * d["flops"] / t / 1e12, 2)}
+    elif name.startswith("conv2d_wino_wgrad["):
+        rocprof_name, extra_name = "k_wino_wgrad@" + name.split("@")[1].rstrip("]"), None
+        extra = {"flops_counted": "executed (Winograd domain)",
+                 "direct_form_equivalent_TFLOP_s": round(2.25 * d["flops"] / t / 1e12, 2)}
     traffic = pmc_traffic(rocprof_name)
     if traffic is not None and extra_name is not None:
         traffic += pmc_traffic(extra_name) or 0.0
@@ -342,7 +380,7 @@ def roofline_of(fam):
             "traffic": traffic,
             "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches_per_step"],
             "algorithmic_flops_per_launch": d["flops"] / d["launches"],
-            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"]}
+            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], **extra}
 
 
 def cpu_baseline(cfg_id, mode):

@@ -11,13 +11,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "pass $c done"
 done
 python3 - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$out/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if "anonymous namespace" not in n or "k_" not in n: continue
-        short = n.split("::")[-1].split("(")[0]
+        m = re.search(r"k_[A-Za-z0-9_]+(<[^(]*>)?", n)      # k_name or k_name<template args>
+        if m is None: continue
+        short = m.group(0)
+        if short.startswith("k_wino_"):     # one kernel, several map sizes: keep them apart by launch size
+            short += "@%s" % r.get("Grid_Size", "?")
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
