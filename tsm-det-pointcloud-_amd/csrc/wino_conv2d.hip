@@ -28,8 +28,6 @@
 //     channels-last rows (512 contiguous bytes per pixel).
 #include "spx_common.h"
 
-#include <type_traits>
-
 // -DWINO_STAMP (dev builds of tools/hip/wino_probe.hip only): s_memtime stamps of one workgroup's waves 0 and 4
 #ifdef WINO_STAMP
 __device__ unsigned long long g_wino_stamps[2][64][16];
@@ -214,26 +212,31 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
     for (int i = 0; i < 4; ++i)
       xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff[i], sc * (kSc * 4), 0));
   };
-  // transforms chunk kk of the super-chunk in xr into V buffer `buf`
-  auto transform_store = [&](int buf, int kk) {
+  // Transform of chunk kk of the super-chunk in xr into V buffer `buf`, in five pieces that the K loop spreads over the
+  // chunk: the column pass (t = B^T d over the patch rows, registers), then one row of positions at a time (row pass across
+  // the quad's lanes with DPP: lane j' gets (t B)[i][j']; 8 bytes to LDS).  Spread out, each piece issues in the shadow of
+  // the partner wave's MFMAs; done in one block at either end of the iteration it was exposed (the f32 MFMA leaves about
+  // four vector issue slots per 64 cycles).
+  f32x2 tcol[4];
+  auto xform_cols = [&](int kk) {
     f32x2 d[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) d[i] = f32x2{xr[i][2 * kk], xr[i][2 * kk + 1]};
-    // column pass (over patch rows): t = B^T d
-    f32x2 t[4];
-    t[0] = d[0] - d[2];
-    t[1] = d[1] + d[2];
-    t[2] = d[2] - d[1];
-    t[3] = d[1] - d[3];
-    // row pass across the quad's lanes: lane j' gets (t B)[i][j']
-    float* dst = vdst + buf * (16 * kTiles * kKc);
+    tcol[0] = d[0] - d[2];
+    tcol[1] = d[1] + d[2];
+    tcol[2] = d[2] - d[1];
+    tcol[3] = d[1] - d[3];
+  };
+  auto xform_row = [&](int buf, int i) {
+    f32x2 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x2 v;
+    for (int e = 0; e < 2; ++e) v[e] = dpp_p(tcol[i][e]) + sgn * dpp_q(tcol[i][e]);
+    *reinterpret_cast<f32x2*>(vdst + buf * (16 * kTiles * kKc) + i * (4 * kTiles * kKc)) = v;
+  };
+  auto transform_store = [&](int buf, int kk) {
+    xform_cols(kk);
 #pragma unroll
-      for (int e = 0; e < 2; ++e) v[e] = dpp_p(t[i][e]) + sgn * dpp_q(t[i][e]);
-      *reinterpret_cast<f32x2*>(dst + i * (4 * kTiles * kKc)) = v;
-    }
+    for (int i = 0; i < 4; ++i) xform_row(buf, i);
   };
   // B fragments of the current chunk; position j's pair is re-loaded for the NEXT chunk right after the MFMAs that read it
   // were issued, so a chunk's weight fetch has a whole chunk of MFMAs to land in and only 8 fragment registers per
@@ -249,27 +252,25 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
   const int stamp_slot = (blockIdx.x == 30 && blockIdx.y == 0) ? (wave == 0 ? 0 : wave == 4 ? 1 : -1) : -1;
   int stamp_c = 0;
 #endif
-  auto mma = [&](int buf, int next_chunk) {
+  // MFMAs of chunk `buf`'s positions; between the positions: the re-load of that position's weights for the next chunk and
+  // one row of the NEXT chunk's transform (into the other buffer)
+  auto mma = [&](int buf, int next_chunk, int kk_next) {
     const float* s = asrc + buf * (16 * kTiles * kKc);
     f32x4 av = *reinterpret_cast<const f32x4*>(s);
+    xform_cols(kk_next);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 an = av;
       if (j < 3) an = *reinterpret_cast<const f32x4*>(s + (j + 1) * (kTiles * kKc));   // next position's A fragment
-      WSTAMP(2 + 3 * j);
 #pragma unroll
       for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < 2; ++nb)
           acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bw[j][nb][st], acc[j][nb], 0, 0, 0);
-#ifdef WINO_STAMP
-          if (st == 0 && nb == 0) WSTAMP(3 + 3 * j);
-#endif
-        }
       load_b(next_chunk, j);
-      WSTAMP(4 + 3 * j);
-      // keep the re-load HERE: left alone, the scheduler sinks all eight loads below the last MFMA of the chunk and the
-      // next chunk then starts by waiting out their L2 latency
+      xform_row(buf ^ 1, j);
+      // keep the re-load and the transform row HERE: left alone, the scheduler sinks all eight loads below the last MFMA of
+      // the chunk and the next chunk then starts by waiting out their L2 latency
       __builtin_amdgcn_sched_barrier(0);
       av = an;
     }
@@ -283,46 +284,19 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
   transform_store(0, 0);
   __syncthreads();
 
-  // One barrier per chunk: iteration c multiplies chunk c out of buffer c&1 while chunk c+1 is transformed into the other
-  // buffer (last read in iteration c-1, i.e. before the barrier that ended it).  The x registers of super-chunk S are
-  // dead after chunk 2S+1 has been transformed (iteration 2S); super-chunk S+1 is fetched right there and first used one
-  // iteration later.  The transform after the last chunk rewrites a buffer nobody reads again.
-  // The two waves of a SIMD take the transform at opposite ends of the iteration — waves 0..3 before their MFMAs, waves
-  // 4..7 after — so that one of them always has MFMAs to issue: done by both at the top, the matrix pipe sat idle for the
-  // length of a transform in every chunk.  Two copies of the loop (not a branch inside one) keep the count of loads in
-  // flight known on each path.
-  auto k_loop = [&](auto early_tag) {
-    constexpr bool kEarly = decltype(early_tag)::value;
-    for (int sc = 0; sc < nsuper; ++sc) {
+  // One barrier per chunk: iteration c multiplies chunk c out of buffer c&1 while chunk c+1 is transformed, row by row
+  // between the positions, into the other buffer (last read in iteration c-1, i.e. before the barrier that ended it).  The x
+  // registers of super-chunk S are dead after chunk 2S+1 has been transformed (iteration 2S); super-chunk S+1 is fetched
+  // right there and first used one iteration later.  The transform after the last chunk rewrites a buffer nobody reads
+  // again.
+  for (int sc = 0; sc < nsuper; ++sc) {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int c = sc * 2 + kk;
-#ifdef WINO_STAMP
-        stamp_c = c;
-#endif
-        WSTAMP(0);
-        if (kEarly) {
-          transform_store(kk ^ 1, kk ^ 1);
-          if (kk == 0) load_x(sc + 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        WSTAMP(1);
-        mma(kk, c + 1);
-        if (!kEarly) {
-          __builtin_amdgcn_sched_barrier(0);
-          transform_store(kk ^ 1, kk ^ 1);
-          if (kk == 0) load_x(sc + 1);
-        }
-        WSTAMP(14);
-        __syncthreads();
-        WSTAMP(15);
-      }
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = sc * 2 + kk;
+      mma(kk, c + 1, kk ^ 1);
+      if (kk == 0) load_x(sc + 1);
+      __syncthreads();
     }
-  };
-  if (__builtin_amdgcn_readfirstlane(half) == 0) {
-    k_loop(std::true_type{});
-  } else {
-    k_loop(std::false_type{});
   }
 
   // ---- output transform.  This wave holds M[i = wrow][j = 0..3]; (M A)[i][0] = M0 + M1 + M2, (M A)[i][1] = M1 - M2 - M3;

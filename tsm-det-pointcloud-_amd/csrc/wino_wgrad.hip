@@ -22,8 +22,6 @@
 // Kernel 2 (k_wino_wgrad_final): sums the splits, applies G^T . G and writes dw with the weight tensor's own strides.
 #include "spx_common.h"
 
-#include <type_traits>
-
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -177,26 +175,30 @@ __global__ void __launch_bounds__(kThreads) k_wino_wgrad(WgradArgs a) {
   };
   float* const v_dst = vs + (x_col * kStepTiles + x_tlo) * kBlk + x_qd * 4;          // + buf, + 4 tiles for item 1
   float* const z_dst = zs + ((2 * z_c) * kStepTiles + z_tl) * kBlk + z_qd * 4;       // + buf, + one j plane for the second
+  // the transform of the loaded step into LDS buffer `buf`, in three pieces (the K loop puts one between each pair of MFMA
+  // groups, where it issues in the shadow of the partner wave's MFMAs)
+  auto xform_x = [&](int buf, int it) {
+    const f32x4 t = xa[it] + sb * xb[it];
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = dpp<qp(0, 1, 2, 1)>(t[e]) + sgn * dpp<qp(2, 2, 1, 3)>(t[e]);
+    *reinterpret_cast<f32x4*>(v_dst + buf * kBufFloats + it * (4 * kBlk)) = v;
+  };
+  auto xform_dy = [&](int buf) {
+    const f32x4 r = a0 * dz[0] + a1 * dz[1];
+    f32x4 p, za, zb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = dpp<qp(1, 0, 3, 2)>(r[e]);
+    // dY column 0 lane: Z[i][0] = r0, Z[i][1] = r0 + r1; column 1 lane: Z[i][2] = r0 - r1, Z[i][3] = -r1
+    za = z_c ? (p - r) : r;
+    zb = z_c ? (-r) : (r + p);
+    *reinterpret_cast<f32x4*>(z_dst + buf * kBufFloats) = za;
+    *reinterpret_cast<f32x4*>(z_dst + buf * kBufFloats + kStepTiles * kBlk) = zb;
+  };
   auto transform_store = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const f32x4 t = xa[it] + sb * xb[it];
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = dpp<qp(0, 1, 2, 1)>(t[e]) + sgn * dpp<qp(2, 2, 1, 3)>(t[e]);
-      *reinterpret_cast<f32x4*>(v_dst + buf * kBufFloats + it * (4 * kBlk)) = v;
-    }
-    {
-      const f32x4 r = a0 * dz[0] + a1 * dz[1];
-      f32x4 p, za, zb;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) p[e] = dpp<qp(1, 0, 3, 2)>(r[e]);
-      // dY column 0 lane: Z[i][0] = r0, Z[i][1] = r0 + r1; column 1 lane: Z[i][2] = r0 - r1, Z[i][3] = -r1
-      za = z_c ? (p - r) : r;
-      zb = z_c ? (-r) : (r + p);
-      *reinterpret_cast<f32x4*>(z_dst + buf * kBufFloats) = za;
-      *reinterpret_cast<f32x4*>(z_dst + buf * kBufFloats + kStepTiles * kBlk) = zb;
-    }
+    xform_x(buf, 0);
+    xform_x(buf, 1);
+    xform_dy(buf);
   };
 
   // ---- MFMA role: position (row, j), output-channel half
@@ -210,6 +212,8 @@ __global__ void __launch_bounds__(kThreads) k_wino_wgrad(WgradArgs a) {
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+  // the 32 MFMAs of step `buf`; after each group of 8: one piece of the NEXT step's transform (into the other buffer), after
+  // the last the loads of the step after next
   auto mma = [&](int buf) {
     const float* pa = a_src + buf * kBufFloats;
     const float* pb = b_src + buf * kBufFloats;
@@ -227,6 +231,11 @@ __global__ void __launch_bounds__(kThreads) k_wino_wgrad(WgradArgs a) {
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int f = 0; f < 2; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[f], acc[e][f], 0, 0, 0);
+      if (q == 0) xform_x(buf ^ 1, 0);
+      if (q == 1) xform_x(buf ^ 1, 1);
+      if (q == 2) xform_dy(buf ^ 1);
+      if (q == 3) issue_loads();
+      __builtin_amdgcn_sched_barrier(0);
       av = an;
       bv = bn;
     }
@@ -237,29 +246,10 @@ __global__ void __launch_bounds__(kThreads) k_wino_wgrad(WgradArgs a) {
     transform_store(0);
     issue_loads();       // step 1 (past the end: every offset out of range, zeros)
     __syncthreads();
-    // one barrier per step; waves 0..3 transform the next step before their MFMAs, waves 4..7 after (see wino_conv2d.hip)
-    auto k_loop = [&](auto early_tag) {
-      constexpr bool kEarly = decltype(early_tag)::value;
-      for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        if (kEarly) {
-          transform_store(buf ^ 1);
-          issue_loads();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        mma(buf);
-        if (!kEarly) {
-          __builtin_amdgcn_sched_barrier(0);
-          transform_store(buf ^ 1);
-          issue_loads();
-        }
-        __syncthreads();
-      }
-    };
-    if (half == 0) {
-      k_loop(std::true_type{});
-    } else {
-      k_loop(std::false_type{});
+    // one barrier per step
+    for (int s = 0; s < nsteps; ++s) {
+      mma(s & 1);
+      __syncthreads();
     }
   }
 
