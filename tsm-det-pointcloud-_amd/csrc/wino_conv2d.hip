@@ -131,15 +131,22 @@ __global__ void k_wino_weight(const float* __restrict__ w, int64_t s_o, int64_t 
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
-  // V[buf 2][pos 16][tile 32][k 8] during the K loop (32 KiB); R[row i 4][tile 32][co 128] in the output transform (64 KiB)
-  __shared__ __attribute__((aligned(16))) float smem[4 * kTiles * kCoWg];
+// NB = 32-column blocks per wave: 2 -> a workgroup covers 128 output channels, 256 registers, one workgroup per CU;
+// 1 -> 64 output channels, 128 registers, TWO workgroups per CU (the epilogue / prologue of one runs under the K loop of the
+// other, and a launch whose workgroup count is a poor multiple of 256 loses less in its last round).
+template <int NB>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 4 : 2, NB == 1 ? 4 : 2)))
+k_wino_conv(WinoArgs a) {
+  constexpr int kCoW = 64 * NB;      // output channels of this workgroup
+  // V[buf 2][pos 16][tile 32][k 8] during the K loop (32 KiB); R[row i 4][tile 32][co] in the output transform
+  constexpr int kSmemFloats = 4 * kTiles * kCoW > 2 * 16 * kTiles * kKc ? 4 * kTiles * kCoW : 2 * 16 * kTiles * kKc;
+  __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wrow = wave & 3;    // transform row i owned by this wave
-  const int half = wave >> 2;   // output-channel half (64) of the workgroup's 128
+  const int half = wave >> 2;   // which half of the workgroup's output channels
   const int l31 = lane & 31, lh = lane >> 5;
 
   // XCD-aware placement: consecutive workgroup ids go to different XCDs; give each XCD a contiguous range of tile blocks
@@ -150,7 +157,8 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
     if (per > 0 && bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
   }
   const int64_t tile0 = (int64_t)bid * kTiles;
-  const int cb = blockIdx.y;
+  const int cbw = blockIdx.y;                    // output-channel block of width kCoW
+  const int nbg = (cbw * 2 + half) * NB;         // this wave's first 32-column block, counted over all of Cout
   const int nchunk = a.cin / kKc;
   const int nsuper = a.cin / kSc;
 
@@ -191,17 +199,17 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
   float* const vdst = smem + (ld_col * kTiles + ld_tile) * kKc + ld_g * 2;   // + buf*16*32*8 + i*4*32*8
 
   // ---- MFMA role
-  // weights of this wave: positions 4*wrow .. +3, column blocks 2*half, 2*half+1 of block cb
+  // weights of this wave: positions 4*wrow .. +3, column blocks nbg .. nbg+NB-1 (block nbg>>2 of 128, sub-block nbg&3)
   const uint32_t u_wave = (uint32_t)__builtin_amdgcn_readfirstlane(
-      (int)(((((int64_t)cb * nchunk * 16 + wrow * 4) * 4 + half * 2) * 256) * 4));   // bytes, wave-uniform
+      (int)(((((int64_t)(nbg >> 2) * nchunk * 16 + wrow * 4) * 4 + (nbg & 3)) * 256) * 4));   // bytes, wave-uniform
   const uint32_t u_lane = (uint32_t)lane * 16u;
   const float* const asrc = smem + (wrow * 4 * kTiles + l31) * kKc + lh * 4;
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][NB];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][nb][r] = 0.f;
 
@@ -241,12 +249,13 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
   // B fragments of the current chunk; position j's pair is re-loaded for the NEXT chunk right after the MFMAs that read it
   // were issued, so a chunk's weight fetch has a whole chunk of MFMAs to land in and only 8 fragment registers per
   // position are live
-  f32x4 bw[4][2];
+  f32x4 bw[4][NB];
   auto load_b = [&](int chunk, int j) {
     chunk = chunk < nchunk ? chunk : nchunk - 1;   // the last chunk re-reads itself: constant load count per iteration
     const int so = (int)u_wave + (chunk * 16 + j) * (kPosFloats * 4);
-    bw[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)u_lane, so, 0));
-    bw[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)u_lane, so + 1024, 0));
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      bw[j][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)u_lane, so + nb * 1024, 0));
   };
 #ifdef WINO_STAMP
   const int stamp_slot = (blockIdx.x == 30 && blockIdx.y == 0) ? (wave == 0 ? 0 : wave == 4 ? 1 : -1) : -1;
@@ -265,7 +274,7 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
 #pragma unroll
       for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
           acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bw[j][nb][st], acc[j][nb], 0, 0, 0);
       load_b(next_chunk, j);
       xform_row(buf ^ 1, j);
@@ -301,34 +310,36 @@ __global__ void __launch_bounds__(kThreads) k_wino_conv(WinoArgs a) {
 
   // ---- output transform.  This wave holds M[i = wrow][j = 0..3]; (M A)[i][0] = M0 + M1 + M2, (M A)[i][1] = M1 - M2 - M3;
   // Y[0][c] = R0 + R1 + R2, Y[1][c] = R1 - R2 - R3 over the four rows i (= waves), which meet in LDS.
-  const int o_q = tid & 31;          // output-channel quad
-  const int o_t = tid >> 5;          // tile 0..15 (+16 in the second pass)
-  const int co0 = cb * kCoWg + o_q * 4;
+  constexpr int kQuads = kCoW / 4;             // output-channel quads of the workgroup
+  constexpr int kTilesPass = kThreads / kQuads;  // tiles combined per pass by the 512 threads
+  const int o_q = tid % kQuads;
+  const int o_t = tid / kQuads;
+  const int co0 = cbw * kCoW + o_q * 4;
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
   if (a.scale) sc4 = *reinterpret_cast<const f32x4*>(a.scale + co0);
   if (a.shift) sh4 = *reinterpret_cast<const f32x4*>(a.shift + co0);
 #pragma unroll
   for (int c2 = 0; c2 < 2; ++c2) {
-    float* r = smem + (wrow * kTiles) * kCoWg + half * 64 + l31;
+    float* r = smem + (wrow * kTiles) * kCoW + half * (32 * NB) + l31;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int trow = (g & 3) + 8 * (g >> 2) + 4 * lh;
         const float v = (c2 == 0) ? (acc[0][nb][g] + acc[1][nb][g] + acc[2][nb][g])
                                   : (acc[1][nb][g] - acc[2][nb][g] - acc[3][nb][g]);
-        r[trow * kCoWg + nb * 32] = v;
+        r[trow * kCoW + nb * 32] = v;
       }
     __syncthreads();
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int tl = o_t + ps * 16;
+    for (int ps = 0; ps < kTiles / kTilesPass; ++ps) {
+      const int tl = o_t + ps * kTilesPass;
       const int64_t t = tile0 + tl;
-      const float* s = smem + tl * kCoWg + o_q * 4;
+      const float* s = smem + tl * kCoW + o_q * 4;
       const f32x4 r0 = *reinterpret_cast<const f32x4*>(s);
-      const f32x4 r1 = *reinterpret_cast<const f32x4*>(s + kTiles * kCoWg);
-      const f32x4 r2 = *reinterpret_cast<const f32x4*>(s + 2 * kTiles * kCoWg);
-      const f32x4 r3 = *reinterpret_cast<const f32x4*>(s + 3 * kTiles * kCoWg);
+      const f32x4 r1 = *reinterpret_cast<const f32x4*>(s + kTiles * kCoW);
+      const f32x4 r2 = *reinterpret_cast<const f32x4*>(s + 2 * kTiles * kCoW);
+      const f32x4 r3 = *reinterpret_cast<const f32x4*>(s + 3 * kTiles * kCoW);
       if (t < a.n_tiles) {
         const int tx = (int)(t % a.tiles_x);
         const int ty = (int)((t / a.tiles_x) % a.tiles_y);
@@ -387,7 +398,15 @@ extern "C" int spx_conv2d_wino(const float* x, int64_t x_ld, const float* u, int
   const int64_t nb = (a.n_tiles + kTiles - 1) / kTiles;
   if (nb > 0x7fffffff) return SPX_ERR_INVALID_ARG;
   a.n_blocks = (int32_t)nb;
-  hipLaunchKernelGGL(k_wino_conv, dim3((unsigned)nb, (unsigned)(cout / kCoWg)), dim3(kThreads), 0, spx_s(stream), a);
+#ifdef WINO_FORCE_NB
+  const bool narrow = WINO_FORCE_NB == 1;
+#else
+  const bool narrow = true;
+#endif
+  if (narrow)
+    hipLaunchKernelGGL(k_wino_conv<1>, dim3((unsigned)nb, (unsigned)(cout / 64)), dim3(kThreads), 0, spx_s(stream), a);
+  else
+    hipLaunchKernelGGL(k_wino_conv<2>, dim3((unsigned)nb, (unsigned)(cout / 128)), dim3(kThreads), 0, spx_s(stream), a);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }

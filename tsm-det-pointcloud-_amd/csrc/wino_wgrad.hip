@@ -85,7 +85,12 @@ __global__ void __launch_bounds__(kThreads) k_wino_wgrad(WgradArgs a) {
   const float a0 = (row == 3) ? 0.0f : 1.0f;
   const float a1 = (row == 0) ? 0.0f : (row == 1 ? 1.0f : -1.0f);
 
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  // the x resource starts ONE PIXEL BEFORE the map: patch column `col` of tile column tx is pixel 2tx - 1 + col, and with
+  // that shift its offset is (scalar: pixel 2tx of the row) + (vector: col pixels) with both parts non-negative — buffer
+  // offsets are unsigned and are not wrapped.  The pixel before the map is never read (those lanes carry the
+  // out-of-range offset).
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x) - a.x_ld, 0, (int)(a.x_bytes + (uint32_t)a.x_ld * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
 
@@ -114,6 +119,12 @@ __global__ void __launch_bounds__(kThreads) k_wino_wgrad(WgradArgs a) {
   int64_t bt = t_begin;
 
   const uint32_t hw = (uint32_t)a.h * (uint32_t)a.w, x_ld4 = (uint32_t)a.x_ld * 4u, dy_ld4 = (uint32_t)a.dy_ld * 4u;
+  // A wave's x items share their tile (x_tlo, x_tlo + 4) and its dy item its tile (z_tl): tile -> pixel arithmetic and the
+  // row / tile validity are wave-uniform and run on the scalar unit; per lane there is only a constant byte offset (patch
+  // column and channels) that goes in the buffer load's vector offset, the tile's base goes in its scalar offset, and the
+  // lanes whose patch column falls off the left / right edge of the map get the out-of-range offset (= zero padding).
+  const uint32_t xv_const = (uint32_t)x_col * x_ld4 + x_chan;     // + scalar: ((nn*H + py)*W + 2tx) * ld4, resource shifted
+  const uint32_t zv_const = (uint32_t)z_c * dy_ld4 + z_chan;      // + scalar: ((nn*H + 2ty)*W + 2tx) * ld4
   f32x4 xa[2], xb[2], dz[2];
   auto issue_loads = [&]() {
     // the step starting at tile bt
@@ -130,16 +141,17 @@ __global__ void __launch_bounds__(kThreads) k_wino_wgrad(WgradArgs a) {
         }
       }
       const bool tv = bt + tl < t_end;
-      const int px = 2 * tx - 1 + x_col;
       const int pya = 2 * ty - 1 + ra, pyb = 2 * ty - 1 + rb;
-      const bool okx = tv && px >= 0 && px < a.w;
-      // 32-bit arithmetic: the host checked that the whole map is < 4 GiB
-      const uint32_t base = ((uint32_t)nn * hw + (uint32_t)px) * x_ld4 + x_chan;
+      // scalar byte offset of pixel (row 0, 2tx) of the frame (in the shifted resource: of pixel 2tx - 1)
+      const uint32_t sbase = ((uint32_t)nn * hw + (uint32_t)(2 * tx)) * x_ld4;
       const uint32_t rowb = (uint32_t)a.w * x_ld4;
-      const uint32_t oa = (okx && pya >= 0 && pya < a.h) ? base + (uint32_t)pya * rowb : kOob;
-      const uint32_t ob = (okx && pyb >= 0 && pyb < a.h) ? base + (uint32_t)pyb * rowb : kOob;
-      xa[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)oa, 0, 0));
-      xb[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)ob, 0, 0));
+      const bool oka = tv && pya >= 0 && pya < a.h, okb = tv && pyb >= 0 && pyb < a.h;
+      // patch columns inside the map: 2tx - 1 + col in [0, W)
+      const int lo = (tx == 0) ? 1 : 0, hi = a.w - (2 * tx - 1);      // valid columns: lo <= col < hi
+      const bool okc = x_col >= lo && x_col < hi;
+      const uint32_t va = (oka && okc) ? xv_const : kOob, vb = (okb && okc) ? xv_const : kOob;
+      xa[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)va, (int)(sbase + (uint32_t)pya * rowb), 0));
+      xb[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vb, (int)(sbase + (uint32_t)pyb * rowb), 0));
     }
     {
       int tx = btx + z_tl, ty = bty, nn = bnn;
@@ -152,14 +164,14 @@ __global__ void __launch_bounds__(kThreads) k_wino_wgrad(WgradArgs a) {
         }
       }
       const bool tv = bt + z_tl < t_end;
-      const int px = 2 * tx + z_c, py = 2 * ty;
-      const bool okx = tv && px < a.w;
+      const int py = 2 * ty;
       const uint32_t rowb = (uint32_t)a.w * dy_ld4;
-      const uint32_t base = (((uint32_t)nn * (uint32_t)a.h + (uint32_t)py) * (uint32_t)a.w + (uint32_t)px) * dy_ld4 + z_chan;
-      const uint32_t o0 = (okx && row != 3) ? base : kOob;                    // row 3 of A dY does not use dY[0]
-      const uint32_t o1 = (okx && row != 0 && py + 1 < a.h) ? base + rowb : kOob;   // row 0 does not use dY[1]
-      dz[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)o0, 0, 0));
-      dz[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)o1, 0, 0));
+      const uint32_t sbase = (((uint32_t)nn * (uint32_t)a.h + (uint32_t)py) * (uint32_t)a.w + (uint32_t)(2 * tx)) * dy_ld4;
+      const bool okc = 2 * tx + z_c < a.w;
+      const uint32_t v0 = (tv && okc && row != 3) ? zv_const : kOob;                     // row 3 of A dY does not use dY[0]
+      const uint32_t v1 = (tv && okc && row != 0 && py + 1 < a.h) ? zv_const : kOob;     // row 0 does not use dY[1]
+      dz[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)v0, (int)sbase, 0));
+      dz[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)v1, (int)(sbase + rowb), 0));
     }
     // advance the scalar tile cursor
     bt += kStepTiles;
@@ -329,7 +341,7 @@ extern "C" int spx_conv2d_wino_wgrad(const float* x, int64_t x_ld, const float* 
   if (tiles_x < kStepTiles) return SPX_ERR_UNSUPPORTED;
   const int64_t x_bytes = ((int64_t)n * h * w - 1) * x_ld * 4 + (int64_t)cin * 4;
   const int64_t dy_bytes = ((int64_t)n * h * w - 1) * dy_ld * 4 + (int64_t)cout * 4;
-  if (x_bytes >= 0xFFFFFFF0ll || dy_bytes >= 0xFFFFFFF0ll) return SPX_ERR_TOO_LARGE;
+  if (x_bytes + x_ld * 4 >= 0xFFFFFFF0ll || dy_bytes >= 0xFFFFFFF0ll) return SPX_ERR_TOO_LARGE;
   const int ns = wgrad_splits(cin, cout);
   if (ws == nullptr || ws_bytes < spx_wino_wgrad_ws_bytes(cin, cout)) return SPX_ERR_WORKSPACE;
   WgradArgs a;
