@@ -80,6 +80,74 @@ def pack_all(convs):
     return True
 
 
+_ASYNC_WGRAD = os.environ.get("SPX_ASYNC_WGRAD", "1") != "0"            # dev knob
+_SIDE_STREAMS = {}
+_JOIN_QUEUED = set()
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device.index)
+    if s is None:
+        s = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
+def _join_after_backward(main, side):
+    """main waits for side once, when the running backward pass has finished (autograd engine callback, as DDP does for its
+    buckets): whatever runs on `main` after loss.backward() — gradient clipping, the optimizer — sees the finished gradients."""
+    key = (main.device.index, main.cuda_stream)
+    if key in _JOIN_QUEUED:
+        return
+
+    def _join():
+        _JOIN_QUEUED.discard(key)
+        main.wait_stream(side)
+
+    _JOIN_QUEUED.add(key)
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
+
+
+
+
+def _off_critical_path(fn, reads, weight):
+    """Weight gradients are not on the critical path of the backward pass — nothing reads them before the optimizer / the
+    gradient all-reduce —, the data gradients are.  fn() (which launches the weight-gradient kernels and returns the
+    gradient tensor) runs on a second stream: its kernels share the chip with whatever the main stream runs next (the
+    memory-bound BatchNorm kernels, the small layers that do not fill it, the last partly empty round of a data gradient).
+    `reads`: tensors fn's kernels read (produced on the main stream; their memory is kept until the side kernels ran).
+    The main stream joins at the end of the backward pass when nothing reads the gradient before (see
+    _nobody_reads_before_the_optimizer), else at once — the kernels then still overlap with the data gradient enqueued
+    just before them."""
+    dev = reads[0].device
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        g = fn()
+    for t in reads:
+        t.record_stream(side)
+    g.record_stream(main)
+    if _nobody_reads_before_the_optimizer(weight):
+        _join_after_backward(main, side)
+    else:
+        main.wait_stream(side)
+    return g
+
+
+def _nobody_reads_before_the_optimizer(weight):
+    """True when the gradient returned for `weight` is only STORED during the backward pass (AccumulateGrad takes the tensor as
+    it is: no kernel) — a leaf parameter without a .grad yet and without hooks.  Everything else reads it on the main stream
+    at once: accumulation into an existing .grad, a non-leaf weight (the gradient travels on through view / permute nodes and
+    is copied into the parameter's layout), tensor hooks, and DistributedDataParallel, whose per-parameter hook copies the
+    gradient into its bucket as soon as it is accumulated (assumed whenever a process group is up)."""
+    if not weight.is_leaf or weight.grad is not None or torch.cuda.is_current_stream_capturing():
+        return False
+    if getattr(weight, "_backward_hooks", None) or getattr(weight, "_post_accumulate_grad_hooks", None):
+        return False
+    dist = torch.distributed
+    return not (dist.is_available() and dist.is_initialized())
+
+
 def _conv(src, wp, c_dst, kvol, pair, ld, n_dst, flip, scale, shift, relu, d_n, rb):
     """One gather-GEMM launch: the MFMA-work-balanced persistent schedule where it applies (plan cached on the rulebook;
     over rows grouped by offset mask for submanifold tables, which several launches share), the one-tile-per-wave
@@ -141,10 +209,15 @@ def _conv_backward(feats, weight, tables, rb, d_n_src, has_bias, dout, needs, d_
         wt = _packed(weight, 1)
         dfe = _conv(dout, wt, cin, kvol, pair_b, ld_b, feats.shape[0], flip_b, None, None, False, d_n_src, rb)
     if needs[1]:
-        counts = None
-        if rb is not None and feats.is_cuda and n_dst > 0 and feats.shape[0] > 0:
-            counts = ops.wgrad_counts_for(rb, pair_f, ld_f, kvol, n_dst, d_n_dst)
-        dw = ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape), d_n_out=d_n_dst, counts=counts)
+        def _wgrad():
+            counts = None
+            if rb is not None and feats.is_cuda and n_dst > 0 and feats.shape[0] > 0:
+                counts = ops.wgrad_counts_for(rb, pair_f, ld_f, kvol, n_dst, d_n_dst)
+            return ops.conv_wgrad(feats, dout, pair_f, ld_f, n_dst, tuple(weight.shape), d_n_out=d_n_dst, counts=counts)
+        if _ASYNC_WGRAD and feats.is_cuda and n_dst > 0 and feats.shape[0] > 0:
+            dw = _off_critical_path(_wgrad, [feats, dout, pair_f], weight)     # enqueued after the data gradient above
+        else:
+            dw = _wgrad()
     if has_bias and needs[2]:
         if d_n_dst is not None:
             # rows beyond the live count are undefined (possibly NaN): select, do not multiply
@@ -370,8 +443,6 @@ def wino_conv2d_ok(x, conv):
 
 
 _WINO_WGRAD = os.environ.get("SPX_BEV_WINOGRAD_WGRAD", "1") != "0"      # dev knob
-
-
 class _WinoConv2dFn(torch.autograd.Function):
     """y = conv2d(x, w, padding=1): forward, data gradient (the same kernel over dy with the rotated / transposed filter
     image) and weight gradient (csrc/wino_wgrad.hip) in the Winograd domain; shapes the weight-gradient kernel does not
@@ -396,7 +467,10 @@ class _WinoConv2dFn(torch.autograd.Function):
                                                          (True, False, False))[0]
         if ctx.needs_input_grad[1]:
             if _WINO_WGRAD and ops.wino_wgrad_ok(weight.shape[1], weight.shape[0], x.shape[3]):
-                dw = ops.conv2d_wino_wgrad(x, dy, weight)
+                if _ASYNC_WGRAD:   # enqueued after the data gradient: that one gets the CUs first, this one what it frees
+                    dw = _off_critical_path(lambda: ops.conv2d_wino_wgrad(x, dy, weight), [x, dy], weight)
+                else:
+                    dw = ops.conv2d_wino_wgrad(x, dy, weight)
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                          (False, True, False))[1]
