@@ -806,8 +806,9 @@ def test_weight_gradients_off_the_critical_path_match_in_stream_order():
         handle.remove()
     for rep in (1, 2):
         for n in grads[0]:
-            # 2e-5: the first layer's weight gradient (4 input channels, atomic slab adds) is not run-to-run exact; a gradient
-            # read before its kernel finished is off by O(1)
+            # 1e-3: with kernels of two streams sharing the chip the atomic adds of the first layer's weight gradient (4 input
+            # channels) land in another order, and train-mode BatchNorm passes that round-off on (seen: 2e-5 .. 5e-5); a
+            # gradient read before its kernel finished is off by O(1)
             d = float((grads[0][n] - grads[rep][n]).abs().max())
-            assert d <= 2e-5 * float(grads[0][n].abs().max()), (rep, n, d, float(grads[0][n].abs().max()))
-    assert seen[0] > 0 and max(abs(v - seen[0]) for v in seen) <= 2e-5 * seen[0]
+            assert d <= 1e-3 * float(grads[0][n].abs().max()), (rep, n, d, float(grads[0][n].abs().max()))
+    assert seen[0] > 0 and max(abs(v - seen[0]) for v in seen) <= 1e-3 * seen[0]
