@@ -277,7 +277,7 @@ class KernelTimer(object):
             flops = 2.0 * 16 * tiles * cin * cout
             nbytes = 4.0 * (n * h * w * (cin + cout) + 16 * cin * cout)
             # the family name carries the launch size (threads) so that the PMC rows of tools/pmc_traffic.sh match it
-            grid = ((tiles + 31) // 32) * (cout // 128) * 512
+            grid = ((tiles + 31) // 32) * (cout // 64) * 512     # csrc/wino_conv2d.hip: 32 tiles x 64 columns per workgroup
             return t._timed("conv2d_wino[%d->%d @%d]" % (cin, cout, grid), flops, nbytes, sv["conv2d_wino"], x, u, cout, scale,
                             shift, relu, out)
 
@@ -363,7 +363,7 @@ def roofline_of(fam):
         rocprof_name = "k_wgrad_mfma<%d, %d," % (_t(ci), _t(co))       # one API call = + k_wgrad_count + k_wgrad_reduce
     extra = {}
     if name.startswith("conv2d_wino["):
-        rocprof_name = "k_wino_conv@" + name.split("@")[1].rstrip("]")
+        rocprof_name = "k_wino_conv<1>@" + name.split("@")[1].rstrip("]")
         extra = {"flops_counted": "executed (Winograd domain: 16 multiply-adds per 2x2 tile and channel pair)",
                  "direct_form_equivalent_TFLOP_s": round(2.25 * d["flops"] / t / 1e12, 2)}
     elif name.startswith("conv2d_wino_wgrad["):
@@ -751,7 +751,8 @@ def main():
                        "miopen": ("immediate mode + the tuned user find/perf db shipped in miopen_db/ (written by MIOpen's own "
                                   "tuner on these convolutions)" if miopen_db else
                                   ("find mode" if args.miopen_find else "immediate mode, system db")),
-                       "execution": ("static row capacities, no host read in the step, rule tables on a second HIP stream"
+                       "execution": ("static row capacities, no host read in the step, rule tables on a second HIP stream, weight "
+                                     "gradients on a third"
                                      + ("; forward + backward replayed as one hipGraph, clip + AdamW eager" if graphed else ""))
                                     if caps is not None else "exact-size sparse tensors"},
         }
@@ -763,11 +764,17 @@ def main():
         # same kernels; at static capacity their grids only carry extra blocks that exit at once)
         step.static_caps = None
         step.graphed = None
+        # ... and every kernel in stream order: in the timed steps the weight-gradient kernels run on a second stream beside
+        # whatever the main stream is doing (spx/functional.py: _off_critical_path), which stretches the kernels they share
+        # the chip with; an event pair around a launch would then time the overlap, not the kernel
+        import spx.functional as _fn
+        _async, _fn._ASYNC_WGRAD = _fn._ASYNC_WGRAD, False
         n_inst = 3
         for i in range(n_inst):
             step(batches[i % len(batches)])
         fam = kt.summary(n_inst)
         kt.uninstall()
+        _fn._ASYNC_WGRAD = _async
         if rank == 0:
             line["roofline"] = roofline_of(fam)
             line["kernels"] = {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"],
