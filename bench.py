@@ -277,7 +277,7 @@ class KernelTimer(object):
             flops = 2.0 * 16 * tiles * cin * cout
             nbytes = 4.0 * (n * h * w * (cin + cout) + 16 * cin * cout)
             # the family name carries the launch size (threads) so that the PMC rows of tools/pmc_traffic.sh match it
-            grid = ((tiles + 31) // 32) * (cout // 64) * 512     # csrc/wino_conv2d.hip: 32 tiles x 64 columns per workgroup
+            grid = ((tiles + 31) // 32 + 7) // 8 * 8 * (cout // 64) * 512     # csrc/wino_conv2d.hip: 32 tiles x 64 columns per workgroup, tile blocks padded to 8
             return t._timed("conv2d_wino[%d->%d @%d]" % (cin, cout, grid), flops, nbytes, sv["conv2d_wino"], x, u, cout, scale,
                             shift, relu, out)
 

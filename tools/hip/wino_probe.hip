@@ -39,21 +39,6 @@ int main() {
     const double us = ms * 1e3 / iters, gf = 2.0 * 9 * c * c * (double)px / 1e9;
     printf("%dx%dx%dx%d: %.1f us  (%.1f TF/s direct-equivalent, %.1f TF/s executed)\n", n, c, h, w, us, gf / us * 1e3,
            gf / 2.25 / us * 1e3);
-#ifdef WINO_STAMP
-    if (si == 0) {
-      static unsigned long long h[2][64][16];
-      hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wino_stamps), sizeof(h));
-      for (int sl = 0; sl < 2; ++sl) {
-        printf("wave %d, per chunk: T | pos j: wait-for-operands, 8 MFMAs + reload (x4) | tail | barrier | total\n", sl * 4);
-        for (int cidx = 2; cidx < 10; ++cidx) {
-          unsigned long long* r = h[sl][cidx];
-          printf("  c%2d: %4llu |", cidx, r[1] - r[0]);
-          for (int j = 0; j < 4; ++j) printf(" %4llu %4llu |", r[3 + 3 * j] - r[2 + 3 * j], r[4 + 3 * j] - r[3 + 3 * j]);
-          printf(" %4llu | %4llu | %5llu\n", r[14] - r[13], r[15] - r[14], r[15] - r[0]);
-        }
-      }
-    }
-#endif
     hipFree(x); hipFree(y); hipFree(u);
   }
   return 0;

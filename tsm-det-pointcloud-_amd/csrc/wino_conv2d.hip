@@ -28,19 +28,6 @@
 //     channels-last rows (512 contiguous bytes per pixel).
 #include "spx_common.h"
 
-// -DWINO_STAMP (dev builds of tools/hip/wino_probe.hip only): s_memtime stamps of one workgroup's waves 0 and 4
-#ifdef WINO_STAMP
-__device__ unsigned long long g_wino_stamps[2][64][16];
-#define WSTAMP(k)                                                                                       \
-  do {                                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (stamp_slot >= 0 && lane == 0 && stamp_c < 64) g_wino_stamps[stamp_slot][stamp_c][k] = __builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-  } while (0)
-#else
-#define WSTAMP(k) do { } while (0)
-#endif
-
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -149,15 +136,15 @@ k_wino_conv(WinoArgs a) {
   const int half = wave >> 2;   // which half of the workgroup's output channels
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // XCD-aware placement: consecutive workgroup ids go to different XCDs; give each XCD a contiguous range of tile blocks
-  // so that the halo pixels two neighbouring blocks share are served by one L2
-  int bid = blockIdx.x;
-  {
-    const int per = a.n_blocks >> 3;
-    if (per > 0 && bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
-  }
+  // Workgroup id -> (tile block, output-channel block).  Consecutive ids go round-robin to the 8 XCDs, each with its own L2;
+  // the workgroups that read the SAME tiles (one per output-channel block) get ids 8 apart: same XCD, back to back, so the
+  // map is fetched into that L2 once, not once per channel block (256 channels: 4 blocks; fetch 220 -> ~70 MB per launch).
+  const int ncb = a.cout / kCoW;
+  const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int cbw = rest % ncb;                    // output-channel block of width kCoW
+  const int bid = (rest / ncb) * 8 + xcd;        // tile block
+  if (bid >= a.n_blocks) return;                 // the grid is padded to a multiple of 8 tile blocks
   const int64_t tile0 = (int64_t)bid * kTiles;
-  const int cbw = blockIdx.y;                    // output-channel block of width kCoW
   const int nbg = (cbw * 2 + half) * NB;         // this wave's first 32-column block, counted over all of Cout
   const int nchunk = a.cin / kKc;
   const int nsuper = a.cin / kSc;
@@ -257,10 +244,6 @@ k_wino_conv(WinoArgs a) {
     for (int nb = 0; nb < NB; ++nb)
       bw[j][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)u_lane, so + nb * 1024, 0));
   };
-#ifdef WINO_STAMP
-  const int stamp_slot = (blockIdx.x == 30 && blockIdx.y == 0) ? (wave == 0 ? 0 : wave == 4 ? 1 : -1) : -1;
-  int stamp_c = 0;
-#endif
   // MFMAs of chunk `buf`'s positions; between the positions: the re-load of that position's weights for the next chunk and
   // one row of the NEXT chunk's transform (into the other buffer)
   auto mma = [&](int buf, int next_chunk, int kk_next) {
@@ -403,10 +386,11 @@ extern "C" int spx_conv2d_wino(const float* x, int64_t x_ld, const float* u, int
 #else
   const bool narrow = true;
 #endif
+  const int64_t nb8 = (nb + 7) / 8 * 8;
   if (narrow)
-    hipLaunchKernelGGL(k_wino_conv<1>, dim3((unsigned)nb, (unsigned)(cout / 64)), dim3(kThreads), 0, spx_s(stream), a);
+    hipLaunchKernelGGL(k_wino_conv<1>, dim3((unsigned)(nb8 * (cout / 64))), dim3(kThreads), 0, spx_s(stream), a);
   else
-    hipLaunchKernelGGL(k_wino_conv<2>, dim3((unsigned)nb, (unsigned)(cout / 128)), dim3(kThreads), 0, spx_s(stream), a);
+    hipLaunchKernelGGL(k_wino_conv<2>, dim3((unsigned)(nb8 * (cout / 128))), dim3(kThreads), 0, spx_s(stream), a);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }
