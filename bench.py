@@ -268,7 +268,7 @@ class KernelTimer(object):
         def pack_weight(weight, mode):
             return t._timed("pack_weight", 0.0, 8.0 * weight.numel(), sv["pack_weight"], weight, mode)
 
-        def conv2d_wino(x, u, cout, scale=None, shift=None, relu=False, out=None):
+        def conv2d_wino(x, u, cout, scale=None, shift=None, relu=False, out=None, stats=False):
             # dense 3x3 conv of the BEV backbone, Winograd F(2x2, 3x3): the kernel EXECUTES 16 multiply-adds per 2x2 output tile
             # and (ci, co) — 4 per output pixel — where the direct form has 9; `flops` is what runs on the MFMA, the
             # direct-form figure is 2.25x that (reported beside it).  bytes: map in + map out + the weight image.
@@ -279,7 +279,7 @@ class KernelTimer(object):
             # the family name carries the launch size (threads) so that the PMC rows of tools/pmc_traffic.sh match it
             grid = ((tiles + 31) // 32 + 7) // 8 * 8 * (cout // 64) * 512     # csrc/wino_conv2d.hip: 32 tiles x 64 columns per workgroup, tile blocks padded to 8
             return t._timed("conv2d_wino[%d->%d @%d]" % (cin, cout, grid), flops, nbytes, sv["conv2d_wino"], x, u, cout, scale,
-                            shift, relu, out)
+                            shift, relu, out, stats)
 
         def conv2d_wino_wgrad(x, dy, like):
             n, cin, h, w = x.shape

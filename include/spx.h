@@ -360,6 +360,14 @@ int spx_bn_apply(const float *x, const float *res, int64_t n, const int64_t *d_n
                  const float *invstd, const float *gamma, const float *beta, int relu, float *y, int64_t y_ld,
                  spx_stream_t stream);
 
+/* Training-mode BatchNorm (+ReLU) from per-block sums taken by the producer of x (spx_conv2d_wino's stat_partials):
+ * partial[nblk][2][c] = sums of x and x*x; finalize + apply, no statistics pass over x.  replaces: the same nn.BatchNorm2d
+ * (train) + nn.ReLU as spx_bn_add_relu_fwd for the 3x3 layers of the BEV backbone, base_bev_backbone.py:38-49. */
+int spx_bn_relu_fwd_from_sums(const float *x, int64_t n, int c, const float *partial, int64_t nblk, const float *gamma,
+                              const float *beta, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                              float momentum, float eps, int relu, float *y, int64_t y_ld, float *save_mean,
+                              float *save_invstd, spx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 9b. Dense 3x3 / stride 1 / pad 1 convolution of the BEV backbone, Winograd F(2x2, 3x3) on the exact-fp32 MFMA
  *    replaces: nn.Conv2d(c, c, kernel_size=3, padding=1, bias=False) forward and its data gradient, reference
@@ -372,12 +380,17 @@ int spx_bn_apply(const float *x, const float *res, int64_t n, const int64_t *d_n
  *    Cout and cout = the layer's Cin; taps are rotated by 180 degrees and the channel roles swapped inside.
  *    cin % 32 == 0 and cout % 128 == 0, else SPX_ERR_INVALID_ARG.
  * spx_conv2d_wino: y = conv3x3(x) with optional epilogue y = relu?(y * scale[co] + shift[co]) (eval BatchNorm folded to
- *    scale/shift; null = identity).  x_ld >= cin, y_ld >= cout, both multiples of 4; x, y 16-byte aligned. */
+ *    scale/shift; null = identity).  x_ld >= cin, y_ld >= cout, both multiples of 4; x, y 16-byte aligned.
+ *    stat_partials (or null): [spx_wino_stat_rows(n, h, w)][2][cout] floats, row b = the sums of y and of y*y over the pixels
+ *    of tile block b — the statistics pass of the training-mode BatchNorm that follows, taken where y is produced
+ *    (spx_bn_relu_fwd_from_sums consumes them). */
+int64_t spx_wino_stat_rows(int32_t n, int32_t h, int32_t w);
 int64_t spx_wino_weight_floats(int32_t cin, int32_t cout);
 int spx_wino_weight(const float *w, int64_t s_o, int64_t s_i, int64_t s_a, int64_t s_b, int32_t cin, int32_t cout, int flip,
                     float *u, spx_stream_t stream);
 int spx_conv2d_wino(const float *x, int64_t x_ld, const float *u, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
-                    const float *scale, const float *shift, int relu, float *y, int64_t y_ld, spx_stream_t stream);
+                    const float *scale, const float *shift, int relu, float *y, int64_t y_ld, float *stat_partials,
+                    spx_stream_t stream);
 
 /* spx_conv2d_wino_wgrad: weight gradient of the same convolution in the Winograd domain (csrc/wino_wgrad.hip):
  *    dw[co*s_o + ci*s_i + a*s_a + b*s_b] = sum over pixels of x[.., ci] (shifted by the tap) * dy[.., co]  — the weight half

@@ -245,3 +245,38 @@ def test_autograd_rectangular_channels_fall_back_per_direction():
     F.conv2d(xr, wr, padding=1).backward(dy.double().cpu())
     _check(x.grad, xr.grad)
     _check(w.grad, wr.grad, tol=5e-5)
+
+
+def test_conv_bn_relu_node_takes_statistics_in_the_conv_epilogue():
+    """_WinoConvBNReLUFn: conv + training-mode BatchNorm + ReLU as one node, the BatchNorm sums taken by the convolution
+    kernel while it stores its output.  Output, running statistics and all four gradients against the torch modules in
+    float64 (BatchNorm parameters chosen so that no ReLU input sits at the kink)."""
+    from spx.functional import wino_conv_bn_relu_train
+    g = torch.Generator().manual_seed(11)
+    conv = torch.nn.Conv2d(128, 128, 3, padding=1, bias=False)
+    bn = torch.nn.BatchNorm2d(128, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / 34)
+        bn.weight.uniform_(0.1, 0.3, generator=g)
+        bn.bias.normal_(2.5, 0.1, generator=g)
+        bn.running_mean.normal_(0, 0.1, generator=g)
+        bn.running_var.uniform_(0.5, 1.5, generator=g)
+    import copy
+    conv64, bn64 = copy.deepcopy(conv).double(), copy.deepcopy(bn).double()
+    conv, bn = conv.cuda().to(memory_format=torch.channels_last), bn.cuda()
+    x = torch.randn((3, 128, 21, 26), generator=g)          # odd height: partly filled tiles in the sums
+    wt = torch.randn((3, 128, 21, 26), generator=g)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = wino_conv_bn_relu_train(xg, conv, bn)
+    (y * wt.cuda()).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    y64 = torch.relu(bn64(conv64(x64)))
+    (y64 * wt.double()).sum().backward()
+    _check(y.detach(), y64.detach())
+    _check(bn.running_mean, bn64.running_mean)
+    _check(bn.running_var, bn64.running_var)
+    assert int(bn.num_batches_tracked) == 1
+    _check(xg.grad, x64.grad, tol=1e-4)
+    _check(conv.weight.grad, conv64.weight.grad, tol=1e-4)
+    _check(bn.weight.grad, bn64.weight.grad, tol=1e-4)
+    _check(bn.bias.grad, bn64.bias.grad, tol=1e-4)

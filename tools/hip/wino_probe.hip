@@ -27,11 +27,11 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) spx_conv2d_wino(x, c, u, n, h, w, c, c, nullptr, nullptr, 0, y, c, nullptr);
+    for (int i = 0; i < 3; ++i) spx_conv2d_wino(x, c, u, n, h, w, c, c, nullptr, nullptr, 0, y, c, nullptr, nullptr);
     hipDeviceSynchronize();
     const int iters = 20;
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; ++i) spx_conv2d_wino(x, c, u, n, h, w, c, c, nullptr, nullptr, 0, y, c, nullptr);
+    for (int i = 0; i < iters; ++i) spx_conv2d_wino(x, c, u, n, h, w, c, c, nullptr, nullptr, 0, y, c, nullptr, nullptr);
     hipEventRecord(e1, nullptr);
     hipEventSynchronize(e1);
     float ms;

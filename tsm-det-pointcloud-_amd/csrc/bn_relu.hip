@@ -254,6 +254,29 @@ extern "C" int spx_bn_add_relu_fwd(const float* x, const float* res, int64_t n, 
   return SPX_OK;
 }
 
+// Training-mode BatchNorm (+ReLU) whose per-channel sums were already taken by the PRODUCER of x — csrc/wino_conv2d.hip
+// writes, per block of 32 output tiles, the sums of y and y*y it stores (partial[nblk][2][C]) — so the statistics pass over x
+// is skipped: finalize (fp64 combine of the rows, running statistics) + apply.
+extern "C" int spx_bn_relu_fwd_from_sums(const float* x, int64_t n, int c, const float* partial, int64_t nblk,
+                                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                         int64_t* num_batches_tracked, float momentum, float eps, int relu, float* y,
+                                         int64_t y_ld, float* save_mean, float* save_invstd, spx_stream_t stream) {
+  if (!x || !partial || !gamma || !beta || !y || !save_mean || !save_invstd || n <= 0 || c <= 0 || nblk <= 0)
+    return SPX_ERR_INVALID_ARG;
+  if (c % 4 != 0 || 1024 % c != 0) return SPX_ERR_UNSUPPORTED;
+  if (nblk > 0x7fffffff) return SPX_ERR_TOO_LARGE;
+  if (y_ld == 0) y_ld = c;
+  if (y_ld < c || y_ld % 4 != 0 || ((uintptr_t)y & 15) != 0) return SPX_ERR_INVALID_ARG;
+  hipStream_t s = spx_s(stream);
+  const int cshift = log2_of(c);
+  hipLaunchKernelGGL(k_bn_finalize, dim3(c), dim3(64), 0, s, partial, (int)nblk, c, n, nullptr, eps, momentum, save_mean,
+                     save_invstd, running_mean, running_var, num_batches_tracked);
+  hipLaunchKernelGGL(k_bn_apply, dim3(bn_blocks(n, c)), dim3(256), 0, s, x, save_mean, save_invstd, gamma, beta, n, nullptr, c,
+                     relu, nullptr, y_ld, cshift, y);
+  SPX_CHECK_LAUNCH();
+  return SPX_OK;
+}
+
 extern "C" int spx_bn_add_relu_bwd(const float* x, const float* res, const float* dy, int64_t dy_ld, int64_t n,
                                    const int64_t* d_n, int c, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                                    int relu, float* dx, float* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,

@@ -48,6 +48,7 @@ struct WinoArgs {
   float* y;            // [N, H, W] pixels, y_ld floats apart
   const float* scale;  // [Cout] or null
   const float* shift;  // [Cout] or null
+  float* stats;        // [n_blocks][2][Cout] per-tile-block sums of y and y*y (BatchNorm statistics), or null
   int64_t x_ld, y_ld;
   uint32_t x_bytes, u_bytes;   // extents of x and u for the buffer resources
   int32_t n, h, w, cin, cout;
@@ -299,6 +300,7 @@ k_wino_conv(WinoArgs a) {
   const int o_t = tid / kQuads;
   const int co0 = cbw * kCoW + o_q * 4;
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
   if (a.scale) sc4 = *reinterpret_cast<const f32x4*>(a.scale + co0);
   if (a.shift) sh4 = *reinterpret_cast<const f32x4*>(a.shift + co0);
 #pragma unroll
@@ -330,6 +332,11 @@ k_wino_conv(WinoArgs a) {
         const int px = 2 * tx + c2;
         f32x4 y0 = (r0 + r1 + r2) * sc4 + sh4;
         f32x4 y1 = (r1 - r2 - r3) * sc4 + sh4;
+        if (a.stats) {   // sums over the pixels this workgroup stores (the statistics of the training-mode BatchNorm that follows)
+          const float m0 = (px < a.w) ? 1.f : 0.f, m1 = (px < a.w && 2 * ty + 1 < a.h) ? 1.f : 0.f;
+          st_s += y0 * m0 + y1 * m1;
+          st_q += y0 * y0 * m0 + y1 * y1 * m1;
+        }
         if (a.relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -347,6 +354,26 @@ k_wino_conv(WinoArgs a) {
     }
     if (c2 == 0) __syncthreads();
   }
+  if (a.stats) {
+    // the kTilesPass threads that share an output-channel quad meet in LDS; thread ch of the first kCoW adds them up in a
+    // fixed order and writes the block's row of partial sums (k_bn_finalize combines the rows in fp64)
+    __syncthreads();
+    float* red = smem;                                  // [kTilesPass][kQuads][8]
+    *reinterpret_cast<f32x4*>(red + (o_t * kQuads + o_q) * 8) = st_s;
+    *reinterpret_cast<f32x4*>(red + (o_t * kQuads + o_q) * 8 + 4) = st_q;
+    __syncthreads();
+    if (tid < kCoW) {
+      const int q = tid >> 2, e = tid & 3;
+      float s1 = 0.f, s2 = 0.f;
+      for (int t = 0; t < kTilesPass; ++t) {
+        s1 += red[(t * kQuads + q) * 8 + e];
+        s2 += red[(t * kQuads + q) * 8 + 4 + e];
+      }
+      float* dst = a.stats + (int64_t)bid * 2 * a.cout + cbw * kCoW + tid;
+      dst[0] = s1;
+      dst[a.cout] = s2;
+    }
+  }
 }
 
 }  // namespace
@@ -363,15 +390,20 @@ extern "C" int spx_wino_weight(const float* w, int64_t s_o, int64_t s_i, int64_t
   return SPX_OK;
 }
 
+extern "C" int64_t spx_wino_stat_rows(int32_t n, int32_t h, int32_t w) {
+  const int64_t tiles = (int64_t)n * ((w + 1) / 2) * ((h + 1) / 2);
+  return (tiles + kTiles - 1) / kTiles;
+}
+
 extern "C" int spx_conv2d_wino(const float* x, int64_t x_ld, const float* u, int32_t n, int32_t h, int32_t w, int32_t cin,
                                int32_t cout, const float* scale, const float* shift, int relu, float* y, int64_t y_ld,
-                               spx_stream_t stream) {
+                               float* stat_partials, spx_stream_t stream) {
   if (n <= 0 || h <= 0 || w <= 0) return SPX_OK;
   if (cin % kSc != 0 || cout % kCoWg != 0 || x_ld < cin || y_ld < cout || (x_ld & 3) || (y_ld & 3)) return SPX_ERR_INVALID_ARG;
   const int64_t x_bytes = ((int64_t)n * h * w - 1) * x_ld * 4 + (int64_t)cin * 4, u_bytes = (int64_t)16 * cin * cout * 4;
   if (x_bytes >= 0xFFFFFFF0ll || u_bytes >= 0x7FFFFFFFll) return SPX_ERR_TOO_LARGE;
   WinoArgs a;
-  a.x = x; a.u = u; a.y = y; a.scale = scale; a.shift = shift;
+  a.x = x; a.u = u; a.y = y; a.scale = scale; a.shift = shift; a.stats = stat_partials;
   a.x_ld = x_ld; a.y_ld = y_ld;
   a.x_bytes = (uint32_t)x_bytes; a.u_bytes = (uint32_t)u_bytes;
   a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from spx import ops
 from spx.functional import (bn_relu_cat_train, bn_relu_train, dense as densify_rows, sparse_conv, wino_conv2d,
-                            wino_conv2d_ok)
+                            wino_conv2d_ok, wino_conv_bn_relu_train)
 
 # below this many activations the three-launch fused BN kernel is launch-bound and MIOpen's BN is faster (measured on
 # MI355X, tools/dense_tail_probe.py: 18 M elements 176 -> 132 us fwd+bwd, 9 M elements 98 -> 123 us)
@@ -42,7 +42,14 @@ def _run_block(seq, x, start=0):
             continue
         if _WINO and isinstance(m, nn.Conv2d) and wino_conv2d_ok(x, m):
             nn2 = mods[i + 2] if i + 2 < len(mods) else None
-            if nxt is not None and isinstance(nn2, nn.ReLU) and _eval_bn_ok(nxt, x, check_layout=False):
+            if (_CONV_BN_NODE and isinstance(nxt, nn.BatchNorm2d) and isinstance(nn2, nn.ReLU) and _train_bn_ok(nxt)
+                    and torch.is_grad_enabled()
+                    and x.shape[0] * x.shape[2] * x.shape[3] * m.out_channels >= _FUSED_BN_MIN_ELEMS
+                    and 1024 % m.out_channels == 0):
+                # training: conv + BN + ReLU as one node; the conv epilogue takes the BN statistics while it stores y
+                x = wino_conv_bn_relu_train(x, m, nxt)
+                i += 3
+            elif nxt is not None and isinstance(nn2, nn.ReLU) and _eval_bn_ok(nxt, x, check_layout=False):
                 scale = nxt.weight * torch.rsqrt(nxt.running_var + nxt.eps)
                 x = wino_conv2d(x, m.weight, scale=scale, shift=nxt.bias - nxt.running_mean * scale, relu=True)
                 i += 3
@@ -74,6 +81,12 @@ _FUSED_EVAL_BN = os.environ.get("SPX_BEV_FUSED_EVAL_BN", "1") != "0"       # dev
 
 
 _WINO = os.environ.get("SPX_BEV_WINOGRAD", "1") != "0"                      # dev knob
+_CONV_BN_NODE = os.environ.get("SPX_BEV_CONV_BN_NODE", "1") != "0"         # dev knob
+
+
+def _train_bn_ok(m):
+    """BatchNorm2d in training mode that libspx's fused kernels cover (affine, running statistics, fixed momentum)."""
+    return m.training and m.affine and m.track_running_stats and m.momentum is not None and m.weight.dtype == torch.float32
 
 
 def _eval_bn_ok(m, x, check_layout=True):

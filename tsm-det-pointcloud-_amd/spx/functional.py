@@ -456,25 +456,66 @@ class _WinoConv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dx = dw = None
-        if ops._cl_ld(dy) is None:
-            dy = dy.contiguous(memory_format=torch.channels_last)
-        if ctx.needs_input_grad[0]:
-            if ops.wino_ok(weight.shape[0], weight.shape[1]):
-                dx = ops.conv2d_wino(dy, _wino_image_always(weight, True), weight.shape[1])
+        return _wino_backward(x, weight, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+
+
+def _wino_backward(x, weight, dy, needs_x, needs_w):
+    """Data gradient and weight gradient of conv2d(x, weight, padding=1) given dy, each on the Winograd kernels when its shape
+    condition holds, else through the vendor library."""
+    dx = dw = None
+    if ops._cl_ld(dy) is None:
+        dy = dy.contiguous(memory_format=torch.channels_last)
+    if needs_x:
+        if ops.wino_ok(weight.shape[0], weight.shape[1]):
+            dx = ops.conv2d_wino(dy, _wino_image_always(weight, True), weight.shape[1])
+        else:
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (True, False, False))[0]
+    if needs_w:
+        if _WINO_WGRAD and ops.wino_wgrad_ok(weight.shape[1], weight.shape[0], x.shape[3]):
+            if _ASYNC_WGRAD:   # enqueued after the data gradient: that one gets the CUs first, this one what it frees
+                dw = _off_critical_path(lambda: ops.conv2d_wino_wgrad(x, dy, weight), [x, dy], weight)
             else:
-                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                         (True, False, False))[0]
-        if ctx.needs_input_grad[1]:
-            if _WINO_WGRAD and ops.wino_wgrad_ok(weight.shape[1], weight.shape[0], x.shape[3]):
-                if _ASYNC_WGRAD:   # enqueued after the data gradient: that one gets the CUs first, this one what it frees
-                    dw = _off_critical_path(lambda: ops.conv2d_wino_wgrad(x, dy, weight), [x, dy], weight)
-                else:
-                    dw = ops.conv2d_wino_wgrad(x, dy, weight)
-            else:
-                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                         (False, True, False))[1]
-        return dx, dw
+                dw = ops.conv2d_wino_wgrad(x, dy, weight)
+        else:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1]
+    return dx, dw
+
+
+class _WinoConvBNReLUFn(torch.autograd.Function):
+    """Conv2d(3x3, padding 1) + training-mode BatchNorm2d + ReLU of one BEV-backbone layer (reference
+    base_bev_backbone.py:45-49) as ONE autograd node.  The convolution kernel's epilogue takes the per-channel sums of y and
+    y*y while it stores y, so BatchNorm needs no statistics pass over the map (one full read of it less per layer)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, nbt, momentum, eps):
+        y, part = ops.conv2d_wino(x, _wino_image(weight, False), weight.shape[0], stats=True)
+        b, c, h, w = y.shape
+        rows = y.permute(0, 2, 3, 1).reshape(b * h * w, c)
+        act, mean, invstd = ops.bn_relu_fwd_from_sums(rows, part, gamma, beta, running_mean, running_var, momentum, eps,
+                                                      True, num_batches_tracked=nbt)
+        ctx.save_for_backward(x, weight, rows, gamma, beta, mean, invstd)
+        ctx.shape = (b, c, h, w)
+        ctx.mark_non_differentiable(running_mean, running_var)
+        return act.view(b, h, w, c).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, da):
+        x, weight, rows, gamma, beta, mean, invstd = ctx.saved_tensors
+        b, c, h, w = ctx.shape
+        da_rows = da.permute(0, 2, 3, 1).reshape(b * h * w, c)
+        drows, dgamma, dbeta = ops.bn_relu_bwd(rows, da_rows, gamma, beta, mean, invstd, True)
+        dy = drows.view(b, h, w, c).permute(0, 3, 1, 2)
+        dx, dw = _wino_backward(x, weight, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
+
+
+def wino_conv_bn_relu_train(x, conv, bn):
+    """relu(bn(conv(x))) for a Winograd-eligible Conv2d and a BatchNorm2d in training mode (affine, running statistics, fixed
+    momentum) as one autograd node."""
+    return _WinoConvBNReLUFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked, bn.momentum, bn.eps)
 
 
 def wino_conv2d(x, weight, scale=None, shift=None, relu=False):

@@ -652,6 +652,24 @@ def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, 
     return y, mean, invstd
 
 
+def bn_relu_fwd_from_sums(x, partial, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None):
+    """bn_relu_fwd for rows x [N, C] whose per-block sums [rows, 2, C] the producing kernel already took (conv2d_wino with
+    stats=True): no statistics pass over x.  Returns y, save_mean, save_invstd."""
+    _need_gpu(x, partial, gamma, beta)
+    lib = _lib.load()
+    x = x.contiguous()
+    n, c = x.shape
+    assert partial.dim() == 3 and partial.shape[1] == 2 and partial.shape[2] == c and partial.is_contiguous()
+    y = torch.empty_like(x)
+    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
+    check(lib.spx_bn_relu_fwd_from_sums(_ptr(x), n, c, _ptr(partial), int(partial.shape[0]), _ptr(gamma), _ptr(beta),
+                                        _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), float(momentum),
+                                        float(eps), int(bool(relu)), _ptr(y), c, _ptr(mean), _ptr(invstd), _stream(x)),
+          "spx_bn_relu_fwd_from_sums")
+    return y, mean, invstd
+
+
 def bn_apply(x, mean, invstd, gamma, beta, relu, residual=None, out=None, d_n=None):
     """Inference-mode BatchNorm (+ residual) (+ReLU) over the rows of x [N, C] with given statistics, one pass.  `out`:
     optional [N, C] row view with its own stride (a channel slice of a wider matrix)."""
@@ -698,10 +716,11 @@ def wino_weight(weight, flip=False, out=None):
     return u
 
 
-def conv2d_wino(x, u, cout, scale=None, shift=None, relu=False, out=None):
+def conv2d_wino(x, u, cout, scale=None, shift=None, relu=False, out=None, stats=False):
     """3x3 / stride 1 / pad 1 convolution of a channels-last map.  x: [N, Cin, H, W] tensor in channels_last memory format
     (or any [N, Cin, H, W] view whose pixels are dense rows: stride (H*W*ld, 1, W*ld, ld)); u: wino_weight image;
-    returns [N, cout, H, W] channels_last (or writes `out`, same layout rule).  Optional epilogue relu?(y*scale + shift)."""
+    returns [N, cout, H, W] channels_last (or writes `out`, same layout rule).  Optional epilogue relu?(y*scale + shift).
+    stats=True: also returns the [rows, 2, cout] per-tile-block sums of y and y*y (bn_relu_fwd_from_sums takes them)."""
     _need_gpu(x, u)
     lib = _lib.load()
     n, cin, h, w = (int(v) for v in x.shape)
@@ -716,9 +735,12 @@ def conv2d_wino(x, u, cout, scale=None, shift=None, relu=False, out=None):
         raise ValueError("out must be a float32 [N, Cout, H, W] channels-last map")
     if u.numel() != lib.spx_wino_weight_floats(cin, cout):
         raise ValueError("weight image does not match Cin=%d, Cout=%d" % (cin, cout))
+    part = None
+    if stats:
+        part = torch.empty((lib.spx_wino_stat_rows(n, h, w), 2, cout), dtype=torch.float32, device=x.device)
     check(lib.spx_conv2d_wino(_ptr(x), x_ld, _ptr(u), n, h, w, cin, cout, _ptr(scale), _ptr(shift), int(bool(relu)),
-                              _ptr(out), y_ld, _stream(x)), "spx_conv2d_wino")
-    return out
+                              _ptr(out), y_ld, _ptr(part), _stream(x)), "spx_conv2d_wino")
+    return (out, part) if stats else out
 
 
 def wino_wgrad_ok(cin, cout, w):
