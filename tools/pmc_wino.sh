@@ -1,8 +1,8 @@
 #!/bin/bash
-# dev tool (GPU box): PMC counters of k_wino_conv from the stand-alone probe (tools/hip/wino_probe.hip, BASE build).
+# dev tool (GPU box): PMC counters of k_wino_conv from the stand-alone probe (tools/hip/wino_probe.hip built to csrc/build/variants/wino_probe).
 # usage: tools/pmc_wino.sh <tag>
 tag=$1
-bin=$GRAFT_REPO_ROOT/tsm-det-pointcloud-_amd/csrc/build/variants/wino_BASE
+bin=$GRAFT_REPO_ROOT/tsm-det-pointcloud-_amd/csrc/build/variants/wino_probe
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_wino_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
