@@ -82,7 +82,6 @@ def pack_all(convs):
 
 _ASYNC_WGRAD = os.environ.get("SPX_ASYNC_WGRAD", "1") != "0"            # dev knob
 _SIDE_STREAMS = {}
-_JOIN_QUEUED = set()
 
 
 def _side_stream(device):
@@ -93,20 +92,11 @@ def _side_stream(device):
 
 
 def _join_after_backward(main, side):
-    """main waits for side once, when the running backward pass has finished (autograd engine callback, as DDP does for its
-    buckets): whatever runs on `main` after loss.backward() — gradient clipping, the optimizer — sees the finished gradients."""
-    key = (main.device.index, main.cuda_stream)
-    if key in _JOIN_QUEUED:
-        return
-
-    def _join():
-        _JOIN_QUEUED.discard(key)
-        main.wait_stream(side)
-
-    _JOIN_QUEUED.add(key)
-    torch.autograd.Variable._execution_engine.queue_callback(_join)
-
-
+    """main waits for side when the running backward pass has finished (autograd engine callback, as DDP does for its
+    buckets): whatever runs on `main` after loss.backward() — gradient clipping, the optimizer — sees the finished gradients.
+    One callback per deferred gradient (a stream wait is a few microseconds of host time): a once-per-pass flag would stay
+    set for ever if a backward pass died with an exception before its callbacks ran, and every later pass would go unjoined."""
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
 
 
 def _off_critical_path(fn, reads, weight):
