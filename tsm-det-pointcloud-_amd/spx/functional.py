@@ -91,12 +91,17 @@ def _side_stream(device):
     return s
 
 
-def _join_after_backward(main, side):
+def _join_after_backward(main, side, keep):
     """main waits for side when the running backward pass has finished (autograd engine callback, as DDP does for its
     buckets): whatever runs on `main` after loss.backward() — gradient clipping, the optimizer — sees the finished gradients.
-    One callback per deferred gradient (a stream wait is a few microseconds of host time): a once-per-pass flag would stay
-    set for ever if a backward pass died with an exception before its callbacks ran, and every later pass would go unjoined."""
-    torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+    `keep`: the tensors the side kernels read; referenced until the join is enqueued, so that the allocator cannot hand their
+    memory to main-stream kernels that would run BEFORE it (after it, stream order protects them).  One callback per deferred
+    gradient (a stream wait is a few microseconds of host time): a once-per-pass flag would stay set for ever if a backward
+    pass died with an exception before its callbacks ran, and every later pass would go unjoined."""
+    def _join():
+        main.wait_stream(side)
+        keep.clear()
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
 def _off_critical_path(fn, reads, weight):
@@ -104,23 +109,20 @@ def _off_critical_path(fn, reads, weight):
     gradient all-reduce —, the data gradients are.  fn() (which launches the weight-gradient kernels and returns the
     gradient tensor) runs on a second stream: its kernels share the chip with whatever the main stream runs next (the
     memory-bound BatchNorm kernels, the small layers that do not fill it, the last partly empty round of a data gradient).
-    `reads`: tensors fn's kernels read (produced on the main stream; their memory is kept until the side kernels ran).
-    The main stream joins at the end of the backward pass when nothing reads the gradient before (see
-    _nobody_reads_before_the_optimizer), else at once — the kernels then still overlap with the data gradient enqueued
-    just before them."""
+    `reads`: tensors fn's kernels read (produced on the main stream).  The main stream joins at the end of the backward pass
+    when nothing reads the gradient before (see _nobody_reads_before_the_optimizer), else at once — the kernels then still
+    overlap with the data gradient enqueued just before them."""
     dev = reads[0].device
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         g = fn()
-    for t in reads:
-        t.record_stream(side)
-    g.record_stream(main)
+    g.record_stream(main)           # allocated in the side stream's pool, consumed (optimizer) and freed on the main stream
     if _nobody_reads_before_the_optimizer(weight):
-        _join_after_backward(main, side)
+        _join_after_backward(main, side, list(reads))
     else:
-        main.wait_stream(side)
+        main.wait_stream(side)      # from here on stream order protects `reads`
     return g
 
 
