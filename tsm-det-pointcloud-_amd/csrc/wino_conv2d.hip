@@ -41,6 +41,8 @@ constexpr int kSc = 16;       // input channels per super-chunk (2 chunks): one 
 constexpr int kCoWg = 128;    // output channels per workgroup
 constexpr int kThreads = 512;
 constexpr int kPosFloats = kCoWg * kKc;   // floats of one (chunk, position) of the weight image
+constexpr int kPlane = kTiles * kKc + 8;  // floats of one position's [tile][k] plane in LDS: + 32 bytes, so that the four
+                                          // patch-column lanes of a quad (four planes) write to different banks
 
 struct WinoArgs {
   const float* x;      // [N, H, W] pixels, x_ld floats apart, Cin used
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(N
 k_wino_conv(WinoArgs a) {
   constexpr int kCoW = 64 * NB;      // output channels of this workgroup
   // V[buf 2][pos 16][tile 32][k 8] during the K loop (32 KiB); R[row i 4][tile 32][co] in the output transform
-  constexpr int kSmemFloats = 4 * kTiles * kCoW > 2 * 16 * kTiles * kKc ? 4 * kTiles * kCoW : 2 * 16 * kTiles * kKc;
+  constexpr int kSmemFloats = 4 * kTiles * kCoW > 2 * 16 * kPlane ? 4 * kTiles * kCoW : 2 * 16 * kPlane;
   __shared__ __attribute__((aligned(16))) float smem[kSmemFloats];
 
   const int tid = threadIdx.x;
@@ -184,14 +186,14 @@ k_wino_conv(WinoArgs a) {
     }
   }
   const float sgn = (ld_col == 1) ? 1.0f : -1.0f;
-  float* const vdst = smem + (ld_col * kTiles + ld_tile) * kKc + ld_g * 2;   // + buf*16*32*8 + i*4*32*8
+  float* const vdst = smem + ld_col * kPlane + ld_tile * kKc + ld_g * 2;   // + buf * 16 planes + i * 4 planes
 
   // ---- MFMA role
   // weights of this wave: positions 4*wrow .. +3, column blocks nbg .. nbg+NB-1 (block nbg>>2 of 128, sub-block nbg&3)
   const uint32_t u_wave = (uint32_t)__builtin_amdgcn_readfirstlane(
       (int)(((((int64_t)(nbg >> 2) * nchunk * 16 + wrow * 4) * 4 + (nbg & 3)) * 256) * 4));   // bytes, wave-uniform
   const uint32_t u_lane = (uint32_t)lane * 16u;
-  const float* const asrc = smem + (wrow * 4 * kTiles + l31) * kKc + lh * 4;
+  const float* const asrc = smem + wrow * 4 * kPlane + l31 * kKc + lh * 4;
 
   f32x16 acc[4][NB];
 #pragma unroll
@@ -227,7 +229,7 @@ k_wino_conv(WinoArgs a) {
     f32x2 v;
 #pragma unroll
     for (int e = 0; e < 2; ++e) v[e] = dpp_p(tcol[i][e]) + sgn * dpp_q(tcol[i][e]);
-    *reinterpret_cast<f32x2*>(vdst + buf * (16 * kTiles * kKc) + i * (4 * kTiles * kKc)) = v;
+    *reinterpret_cast<f32x2*>(vdst + buf * (16 * kPlane) + i * (4 * kPlane)) = v;
   };
   auto transform_store = [&](int buf, int kk) {
     xform_cols(kk);
@@ -248,13 +250,13 @@ k_wino_conv(WinoArgs a) {
   // MFMAs of chunk `buf`'s positions; between the positions: the re-load of that position's weights for the next chunk and
   // one row of the NEXT chunk's transform (into the other buffer)
   auto mma = [&](int buf, int next_chunk, int kk_next) {
-    const float* s = asrc + buf * (16 * kTiles * kKc);
+    const float* s = asrc + buf * (16 * kPlane);
     f32x4 av = *reinterpret_cast<const f32x4*>(s);
     xform_cols(kk_next);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 an = av;
-      if (j < 3) an = *reinterpret_cast<const f32x4*>(s + (j + 1) * (kTiles * kKc));   // next position's A fragment
+      if (j < 3) an = *reinterpret_cast<const f32x4*>(s + (j + 1) * kPlane);   // next position's A fragment
 #pragma unroll
       for (int st = 0; st < 4; ++st)
 #pragma unroll
