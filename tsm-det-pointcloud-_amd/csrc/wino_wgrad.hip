@@ -12,7 +12,8 @@
 // block of (ci, co) x a contiguous range of tiles (the K dimension, split over workgroups so the launch fills the chip).
 //   * wave (j, half): position (i, j); accumulators 4 ci-blocks x 2 co-blocks of 32x32 = 128 registers.  A fragment lane
 //     m' holds channels 4m'..4m'+3 of ONE tile as one ds_read_b128: component e is MFMA row-block e, i.e. row-block e
-//     is the channels = e (mod 4) — the permutation is undone when the partial result is stored.  Likewise co.  So both
+//     is the channels = e (mod 4) — the permutation is undone when the partial result is stored.  (A wave's 64 output
+//     channels are contiguous: lane n' holds the pair 2n', 2n'+1.)  So both
 //     transformed operands sit in LDS in their natural [tile][channel] order: no transpose anywhere.
 //   * per step of 8 tiles: every thread fetches 2 patch rows x 16 bytes for two (tile, patch column, channel quad) items
 //     and 2 dY rows x 16 bytes for one (tile, dY column, channel quad) item (buffer loads: out-of-map = 0 = the zero
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(kThreads) k_wino_wgrad(WgradArgs a) {
   // ---- MFMA role: position (row, j), output-channel half
   const int j = wave & 3, half = wave >> 2;
   const float* const a_src = vs + (j * kStepTiles + lh) * kBlk + l31 * 4;
-  const float* const b_src = zs + (j * kStepTiles + lh) * kBlk + l31 * 4 + half * 2;
+  const float* const b_src = zs + (j * kStepTiles + lh) * kBlk + half * 64 + l31 * 2;
   f32x16 acc[4][2];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -265,8 +266,10 @@ __global__ void __launch_bounds__(kThreads) k_wino_wgrad(WgradArgs a) {
     }
   }
 
-  // ---- partial result: acc[e][f][r] is (ci = 4 m' + e, co = 4 n' + 2 half + f), m' = row of register r, n' = lane & 31
-  float* const out = a.part + (((int64_t)split * 16 + row * 4 + j) * a.cin + cib * kBlk) * a.cout + cob * kBlk + l31 * 4 + half * 2;
+  // ---- partial result: acc[e][f][r] is (ci = 4 m' + e, co = 64 half + 2 n' + f), m' = row of register r, n' = lane & 31: a
+  // wave's store instruction covers 256 contiguous bytes of a row (whole 128-byte lines: with the two halves interleaved at
+  // 8 bytes, as first written, the PMC write size was twice the 64 MB of partials)
+  float* const out = a.part + (((int64_t)split * 16 + row * 4 + j) * a.cin + cib * kBlk) * a.cout + cob * kBlk + half * 64 + l31 * 2;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
