@@ -139,14 +139,17 @@ k_wino_conv(WinoArgs a) {
   const int half = wave >> 2;   // which half of the workgroup's output channels
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // Workgroup id -> (tile block, output-channel block).  Consecutive ids go round-robin to the 8 XCDs, each with its own L2;
-  // the workgroups that read the SAME tiles (one per output-channel block) get ids 8 apart: same XCD, back to back, so the
-  // map is fetched into that L2 once, not once per channel block (256 channels: 4 blocks; fetch 220 -> ~70 MB per launch).
+  // Workgroup id -> (tile block, output-channel block).  Consecutive ids go round-robin to the 8 XCDs, each with its own L2.
+  // An XCD gets a CONTIGUOUS range of tile blocks — vertically adjacent tiles share two of their four patch rows, and a
+  // tile row is 2-3 blocks long, so the sharers run on the same L2 within a few workgroup slots — and, for each tile
+  // block, all its output-channel blocks back to back (they read the same pixels).  Round-robin over tile blocks fetched
+  // every map 2.6 (128 channels) to 6 times (256 channels) into the L2s.
   const int ncb = a.cout / kCoW;
   const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int per = (a.n_blocks + 7) >> 3;         // tile blocks per XCD (the grid is padded to 8 * per * ncb)
   const int cbw = rest % ncb;                    // output-channel block of width kCoW
-  const int bid = (rest / ncb) * 8 + xcd;        // tile block
-  if (bid >= a.n_blocks) return;                 // the grid is padded to a multiple of 8 tile blocks
+  const int bid = xcd * per + rest / ncb;        // tile block
+  if (bid >= a.n_blocks) return;
   const int64_t tile0 = (int64_t)bid * kTiles;
   const int nbg = (cbw * 2 + half) * NB;         // this wave's first 32-column block, counted over all of Cout
   const int nchunk = a.cin / kKc;
