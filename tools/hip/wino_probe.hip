@@ -1,4 +1,4 @@
-// wino_probe.hip — dev probe (GPU box): times k_wino_conv of csrc/wino_conv2d.hip stand-alone on the BEV shapes, built
+// wino_probe.hip — dev probe (GPU box): times k_wino_conv of csrc/wino_conv2d.hip stand-alone on the BEV shapes
 // (no torch, no dispatcher: the kernel's own time under hipEvents).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DWINO_FORCE_NB=2] tools/hip/wino_probe.hip -o /tmp/wino_probe && /tmp/wino_probe
 // (the -DWINO_NO_* / -DWINO_STAMP builds that located the round-2 bottlenecks lived in the kernel source while it was being
