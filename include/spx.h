@@ -235,6 +235,26 @@ int spx_conv_gemm_balanced(const float *src, int c_src, const float *w_packed, i
                            const float *scale, const float *shift, int relu, int32_t *plan, const int32_t *perm,
                            float *dst, void *ws, size_t ws_bytes, spx_stream_t stream);
 
+/* Round-3 schedule of the same product (csrc/conv_ring.hip): every 16-row tile belongs to ONE wave for the whole launch
+ * (no tile is split between workgroups: no partial-sum slabs, no tickets), the K weight slices stream through an LDS ring
+ * filled by a loader wave, consumers run barrier-free.  spx_conv_ring_plan (cached per rule table, like spx_conv_plan) deals
+ * the tiles to the chip's 1024 SIMDs by their number of non-empty offsets; the plan is written by the planning kernels only
+ * (one debug counter aside), so any number of launches may share it.  pair / perm: exactly as spx_conv_gemm_balanced
+ * (a table grouped by spx_conv_group, or the plain table with perm = NULL).  n_src = rows of `src` (entries are bounds-checked
+ * against it by the buffer hardware: an entry of -1 reads zeros).  stats (nullable): [spx_conv_ring_stat_rows()][2][c_dst]
+ * floats, row b = column sums of the written values and of their squares over the rows workgroup b wrote — the statistics
+ * pass of the training-mode BatchNorm1d that follows (reference spconv_backbone.py:26-27,81), consumed by
+ * spx_bn_relu_fwd_from_sums.  Every output row is the same sum over k in ascending order whatever the plan: bitwise
+ * reproducible.  Channel pairs: (32|64) x (32|64); others SPX_ERR_UNSUPPORTED.  kvol <= 31. */
+size_t spx_conv_ring_plan_bytes(int64_t n_dst);
+int spx_conv_ring_stat_rows(void);
+int spx_conv_ring_plan(const int32_t *pair, int64_t pair_ld, int kvol, int64_t n_dst, const int64_t *d_n_dst, int32_t *plan,
+                       spx_stream_t stream);
+int spx_conv_gemm_ring(const float *src, int64_t n_src, int c_src, const float *w_packed, int c_dst, int kvol, int flip_k,
+                       const int32_t *pair, int64_t pair_ld, int64_t n_dst, const int64_t *d_n_dst, const float *scale,
+                       const float *shift, int relu, int32_t *plan, const int32_t *perm, float *dst, float *stats,
+                       spx_stream_t stream);
+
 size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n_out);
 /* counts (nullable): the table's pair counts from spx_conv_wgrad_counts (device, spx_conv_wgrad_counts_bytes); they depend on
  * the rule table only, so a table that serves several layers / steps of a replayed graph is counted once.  NULL: counted

@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--what", default="fwd,dgrad,wgrad,rulebook")
     ap.add_argument("--layers", default="")
     ap.add_argument("--balanced", action="store_true", help="fwd/dgrad through the balanced persistent schedule")
+    ap.add_argument("--ring", action="store_true", help="also time the round-3 ring schedule (csrc/conv_ring.hip), 64x64")
     ap.add_argument("--group", type=int, default=0,
                     help="with --balanced: also time the schedule over rows grouped by offset mask inside windows of this "
                          "many rows (-1: one window)")
@@ -141,6 +142,24 @@ def main():
                     line += " | fwd grouped %7.1f us (units %d -> %d, err %.1e)" % (tg * 1e6, int(plan[1]), int(plang[1]), err)
             else:
                 t = timeit(lambda: ops.conv_gemm(x, wp, cout, K, rb.pair, rb.ld, rb.n_out), args.iters)
+            if args.ring and ops.ring_ok(cin, cout, rb.n_out, K):
+                ref = ops.conv_gemm(x, wp, cout, K, rb.pair, rb.ld, rb.n_out)
+                rplan = ops.conv_ring_plan(rb.pair, rb.ld, K, rb.n_out)
+                fr = (lambda: ops.conv_gemm_ring(x, wp, cout, K, rb.pair, rb.ld, rb.n_out, rplan))
+                err = float((fr() - ref).abs().max())
+                tr_ = timeit(fr, args.iters)
+                tp = timeit(lambda: ops.conv_ring_plan(rb.pair, rb.ld, K, rb.n_out), args.iters)
+                line += " | fwd ring %7.1f us %6.2f TF/s (err %.1e, plan %.1f us, timeouts %d)" % (
+                    tr_ * 1e6, flops / tr_ / 1e12, err, tp * 1e6, int(rplan[2]))
+                perm, pp = ops.conv_group(rb.pair, rb.ld, K, rb.n_out)
+                gplan = ops.conv_ring_plan(pp, rb.n_out, K, rb.n_out)
+                fg2 = (lambda: ops.conv_gemm_ring(x, wp, cout, K, pp, rb.n_out, rb.n_out, gplan, perm=perm))
+                err = float((fg2() - ref).abs().max())
+                tg2 = timeit(fg2, args.iters)
+                out_s, st = ops.conv_gemm_ring(x, wp, cout, K, pp, rb.n_out, rb.n_out, gplan, perm=perm, want_stats=True)
+                serr = float((st.double().sum(0)[0] - out_s.double().sum(0)).abs().max() / out_s.double().abs().sum(0).max())
+                line += " | fwd ring grouped %7.1f us %6.2f TF/s (err %.1e, stats %.1e, units %d)" % (
+                    tg2 * 1e6, flops / tg2 / 1e12, err, serr, int(gplan[1]))
             tot["fwd"] += t
             tot["flops"] += flops
             line += " | fwd %7.1f us %6.2f TF/s %6.0f GB/s" % (t * 1e6, flops / t / 1e12, nbytes / t / 1e9)
@@ -160,6 +179,13 @@ def main():
                 f = (lambda: ops.conv_gemm(dout, wt, cin, K, rb.pair, rb.ld, rb.n_in, flip_k=True))
             else:
                 f = (lambda: ops.conv_gemm(dout, wt, cin, K, rb.pair_bwd, rb.pair_bwd.shape[1], rb.n_in))
+            if args.ring and ops.ring_ok(cout, cin, rb.n_in, K):
+                tb, ldb = (rb.pair, rb.ld) if rb.subm else (rb.pair_bwd, rb.pair_bwd.shape[1])
+                refb = ops.conv_gemm(dout, wt, cin, K, tb, ldb, rb.n_in, flip_k=rb.subm)
+                rplanb = ops.conv_ring_plan(tb, ldb, K, rb.n_in)
+                frb = (lambda: ops.conv_gemm_ring(dout, wt, cin, K, tb, ldb, rb.n_in, rplanb, flip_k=rb.subm))
+                errb = float((frb() - refb).abs().max())
+                line += " | dgrad ring %7.1f us (err %.1e)" % (timeit(frb, args.iters) * 1e6, errb)
             t = timeit(f, args.iters)
             tot["dgrad"] += t
             line += " | dgrad %7.1f us %6.2f TF/s" % (t * 1e6, flops / t / 1e12)

@@ -140,21 +140,33 @@ def _nobody_reads_before_the_optimizer(weight):
     return not (dist.is_available() and dist.is_initialized())
 
 
-def _conv(src, wp, c_dst, kvol, pair, ld, n_dst, flip, scale, shift, relu, d_n, rb):
-    """One gather-GEMM launch: the MFMA-work-balanced persistent schedule where it applies (plan cached on the rulebook;
-    over rows grouped by offset mask for submanifold tables, which several launches share), the one-tile-per-wave
-    kernel otherwise."""
-    if (rb is not None and src.is_cuda and n_dst > 0 and src.shape[0] > 0
-            and ops.balanced_ok(src.shape[1], c_dst, n_dst, rb, pair)):
-        if ops.grouped_ok(rb, kvol):
-            perm, grouped, plan = ops.grouped_plan_for(rb, pair, ld, kvol, n_dst, d_n)
-            return ops.conv_gemm_balanced(src, wp, c_dst, kvol, grouped, n_dst, n_dst, plan, flip_k=flip, scale=scale,
-                                          shift=shift, relu=relu, d_n_dst=d_n, perm=perm)
-        plan = ops.plan_for(rb, pair, ld, kvol, n_dst, d_n)
-        return ops.conv_gemm_balanced(src, wp, c_dst, kvol, pair, ld, n_dst, plan, flip_k=flip, scale=scale, shift=shift,
-                                      relu=relu, d_n_dst=d_n)
-    return ops.conv_gemm(src, wp, c_dst, kvol, pair, ld, n_dst, flip_k=flip, scale=scale, shift=shift, relu=relu,
-                         d_n_dst=d_n)
+def _conv(src, wp, c_dst, kvol, pair, ld, n_dst, flip, scale, shift, relu, d_n, rb, want_stats=False):
+    """One gather-GEMM launch: the ring schedule (round 3: every tile owned by one wave, csrc/conv_ring.hip) for the 64-channel
+    layers, the MFMA-work-balanced persistent schedule where that one applies (128-channel BEV entry conv), the
+    one-tile-per-wave kernel otherwise; plans are cached on the rulebook, over rows grouped by offset mask for submanifold
+    tables (which several launches share).  want_stats: return (out, stats) where stats is the [rows, 2, c_dst] per-workgroup
+    column sums of out and out**2 when the launch took them in its epilogue, else None."""
+    out = stats = None
+    if rb is not None and src.is_cuda and n_dst > 0 and src.shape[0] > 0:
+        if ops.ring_ok(src.shape[1], c_dst, n_dst, kvol):
+            perm, table, tld, plan = ops.ring_plan_for(rb, pair, ld, kvol, n_dst, d_n)
+            out = ops.conv_gemm_ring(src, wp, c_dst, kvol, table, tld, n_dst, plan, flip_k=flip, scale=scale, shift=shift,
+                                     relu=relu, d_n_dst=d_n, perm=perm, want_stats=want_stats)
+            if want_stats:
+                out, stats = out
+        elif ops.balanced_ok(src.shape[1], c_dst, n_dst, rb, pair):
+            if ops.grouped_ok(rb, kvol):
+                perm, grouped, plan = ops.grouped_plan_for(rb, pair, ld, kvol, n_dst, d_n)
+                out = ops.conv_gemm_balanced(src, wp, c_dst, kvol, grouped, n_dst, n_dst, plan, flip_k=flip, scale=scale,
+                                             shift=shift, relu=relu, d_n_dst=d_n, perm=perm)
+            else:
+                plan = ops.plan_for(rb, pair, ld, kvol, n_dst, d_n)
+                out = ops.conv_gemm_balanced(src, wp, c_dst, kvol, pair, ld, n_dst, plan, flip_k=flip, scale=scale,
+                                             shift=shift, relu=relu, d_n_dst=d_n)
+    if out is None:
+        out = ops.conv_gemm(src, wp, c_dst, kvol, pair, ld, n_dst, flip_k=flip, scale=scale, shift=shift, relu=relu,
+                            d_n_dst=d_n)
+    return (out, stats) if want_stats else out
 
 
 class _SparseConvFn(torch.autograd.Function):

@@ -452,6 +452,65 @@ def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k
     return dst
 
 
+_RING = os.environ.get("SPX_CONV_RING", "1") != "0"              # dev knob: round-3 schedule (csrc/conv_ring.hip)
+_RING_SHAPES = {(64, 64)}
+if os.environ.get("SPX_CONV_RING_SHAPES"):                       # dev knob: "32x32,32x64,64x32,64x64"
+    _RING_SHAPES = {tuple(int(v) for v in t.split("x")) for t in os.environ["SPX_CONV_RING_SHAPES"].split(",")}
+_RING_MIN_ROWS = int(os.environ.get("SPX_CONV_RING_MIN_ROWS", "24000"))
+
+
+def ring_ok(c_src, c_dst, n_dst, kvol):
+    return _RING and (c_src, c_dst) in _RING_SHAPES and n_dst >= _RING_MIN_ROWS and kvol <= 31
+
+
+def conv_ring_plan(pair, ld, kvol, n_dst, d_n_dst=None):
+    """Tile -> wave assignment of the ring schedule for one rule table (include/spx.h: spx_conv_ring_plan)."""
+    _need_gpu(pair)
+    lib = _lib.load()
+    plan = torch.empty((lib.spx_conv_ring_plan_bytes(n_dst) // 4,), dtype=torch.int32, device=pair.device)
+    check(lib.spx_conv_ring_plan(_ptr(pair), ld, kvol, n_dst, _ptr(d_n_dst), _ptr(plan), _stream(pair)),
+          "spx_conv_ring_plan")
+    return plan
+
+
+def ring_plan_for(rb, pair, ld, kvol, n_dst, d_n_dst=None):
+    """(perm, table, ring plan) of rule table `pair`, built once per Rulebook and table: over the grouped rows for submanifold
+    tables (perm != None), over the plain table otherwise."""
+    key = ("r", pair.data_ptr(), int(n_dst))
+    hit = rb._plans.get(key)
+    if hit is None:
+        if grouped_ok(rb, kvol):
+            gkey = ("g", pair.data_ptr(), int(n_dst))
+            ghit = rb._plans.get(gkey)
+            if ghit is not None:
+                perm, grouped = ghit[0], ghit[1]
+            else:
+                perm, grouped = conv_group(pair, ld, kvol, n_dst, d_n_dst)
+            hit = (perm, grouped, n_dst, conv_ring_plan(grouped, n_dst, kvol, n_dst, d_n_dst))
+        else:
+            hit = (None, pair, ld, conv_ring_plan(pair, ld, kvol, n_dst, d_n_dst))
+        rb._plans[key] = hit
+    return hit
+
+
+def conv_gemm_ring(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k=False, scale=None, shift=None, relu=False,
+                   d_n_dst=None, perm=None, want_stats=False):
+    """conv_gemm under the ring schedule (`plan` from conv_ring_plan on the same table / n_dst).  want_stats: also return the
+    per-workgroup column sums [rows, 2, c_dst] of the written values and their squares."""
+    _need_gpu(src, w_packed, pair, plan)
+    lib = _lib.load()
+    src = src.contiguous()
+    assert src.dtype == torch.float32 and n_dst > 0 and src.shape[0] > 0
+    dst = torch.empty((n_dst, c_dst), dtype=torch.float32, device=src.device)
+    stats = None
+    if want_stats:
+        stats = torch.empty((lib.spx_conv_ring_stat_rows(), 2, c_dst), dtype=torch.float32, device=src.device)
+    check(lib.spx_conv_gemm_ring(_ptr(src), src.shape[0], src.shape[1], _ptr(w_packed), c_dst, kvol, int(bool(flip_k)),
+                                 _ptr(pair), ld, n_dst, _ptr(d_n_dst), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(plan),
+                                 _ptr(perm), _ptr(dst), _ptr(stats), _stream(src)), "spx_conv_gemm_ring")
+    return (dst, stats) if want_stats else dst
+
+
 def wgrad_counts(pair, ld, kvol, n_out, d_n_out=None):
     """Pair counts of a rule table for conv_wgrad's work split (include/spx.h: spx_conv_wgrad_counts); int32 device tensor."""
     _need_gpu(pair)

@@ -38,6 +38,9 @@ def _plans(rb, conv, backward):
     if backward and rb.n_out > 0 and rb.n_in > 0:
         ops.wgrad_counts_for(rb, rb.pair, rb.ld, kvol, rb.n_out, rb.d_n_out)      # the weight gradient's work split
     for c_src, c_dst, pair, ld, n_dst, d_n in jobs:
+        if n_dst > 0 and ops.ring_ok(c_src, c_dst, n_dst, kvol):
+            ops.ring_plan_for(rb, pair, ld, kvol, n_dst, d_n)
+            continue
         if n_dst <= 0 or not ops.balanced_ok(c_src, c_dst, n_dst, rb, pair):
             continue
         if ops.grouped_ok(rb, kvol):
