@@ -174,18 +174,45 @@ class KernelTimer(object):
             self._pairs[key] = int((pair[:, :n] >= 0).sum().item())
         return self._pairs[key]
 
+    def _S(self, pair, n):
+        """Live source rows of a rule table = 1 + the largest row it refers to (every live row of the layers measured here is
+        some destination's neighbour); used where the caller runs at static capacity and src.shape[0] is the capacity."""
+        key = ("s", pair.data_ptr(), int(n))
+        if key not in self._pairs:
+            self._pairs[key] = int(pair[:, :n].max().item()) + 1 if n > 0 else 0
+        return self._pairs[key]
+
+    def _conv_work(self, src, c_dst, kvol, pair, n_dst, d_n, d_n_src=None):
+        """(flops, bytes) of one gather-GEMM per SURVEY.md section 8(d), as callables over the LIVE row counts."""
+        cs = src.shape[1]
+
+        def flops():
+            return 2.0 * self._P(pair, self._live(d_n, n_dst)) * cs * c_dst
+
+        def nbytes():
+            nd = self._live(d_n, n_dst)
+            ns = src.shape[0] if d_n is None else min(src.shape[0], self._S(pair, nd))   # static capacity: live source rows
+            return 4.0 * (ns * cs + nd * c_dst + kvol * cs * c_dst + kvol * nd)
+        return flops, nbytes
+
     def _timed(self, family, flops, nbytes, fn, *a, **k):
+        """flops / nbytes: numbers, or callables evaluated after the launch has been timed (they may read device-side row
+        counts: a host sync between the two events would be timed as kernel time)."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn(*a, **k)
         e1.record()
-        self.rec.append((family, flops, nbytes, e0, e1))
+        self.rec.append((family, flops, nbytes, e0, e1, out))
         return out
+
+    @staticmethod
+    def _live(d_n, n):
+        return n if d_n is None else min(int(d_n.item()), int(n))
 
     def install(self):
         from spx import ops
         t = self
-        names = ["conv_gemm", "conv_gemm_balanced", "conv_plan", "conv_group", "conv_wgrad", "subm_rulebook", "conv_rulebook", "voxelize",
+        names = ["conv_gemm", "conv_gemm_balanced", "conv_gemm_ring", "conv_ring_plan", "conv_plan", "conv_group", "conv_wgrad", "subm_rulebook", "conv_rulebook", "voxelize",
                  "densify", "densify_bwd", "pack_weight", "conv2d_wino", "conv2d_wino_wgrad", "wino_weight"]
         self._saved = {n: getattr(ops, n) for n in names}
         sv = self._saved
@@ -193,9 +220,7 @@ class KernelTimer(object):
         def conv_gemm(src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k=False, scale=None, shift=None, relu=False,
                       d_n_dst=None):
             cs = src.shape[1]
-            P = t._P(pair, n_dst)
-            flops = 2.0 * P * cs * c_dst
-            nbytes = 4.0 * (src.shape[0] * cs + n_dst * c_dst + kvol * cs * c_dst + kvol * n_dst)
+            flops, nbytes = t._conv_work(src, c_dst, kvol, pair, n_dst, d_n_dst)
             # one family per template instantiation, named so that it maps 1:1 to a rocprofv3 row (k_conv_mfma<cs, cd, ..>)
             fam = "conv_gemm[mfma %dx%d]" % (cs, c_dst) if (cs % 16 == 0 and c_dst % 16 == 0) else "conv_gemm[valu]"
             return t._timed(fam, flops, nbytes, sv["conv_gemm"], src, w_packed, c_dst, kvol, pair, ld, n_dst, flip_k,
@@ -203,26 +228,42 @@ class KernelTimer(object):
 
         def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k=False, scale=None, shift=None,
                                relu=False, d_n_dst=None, perm=None):
-            P = t._P(pair, n_dst)
             cs = src.shape[1]
-            flops = 2.0 * P * cs * c_dst
-            nbytes = 4.0 * (src.shape[0] * cs + n_dst * c_dst + kvol * cs * c_dst + kvol * n_dst)
+            flops, nbytes = t._conv_work(src, c_dst, kvol, pair, n_dst, d_n_dst)
             return t._timed("conv_gemm[mfma %dx%d balanced]" % (cs, c_dst), flops, nbytes, sv["conv_gemm_balanced"], src, w_packed,
                             c_dst, kvol, pair, ld, n_dst, plan, flip_k, scale, shift, relu, d_n_dst, perm)
 
+        def conv_gemm_ring(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k=False, scale=None, shift=None,
+                           relu=False, d_n_dst=None, perm=None, want_stats=False):
+            cs = src.shape[1]
+            flops, nbytes = t._conv_work(src, c_dst, kvol, pair, n_dst, d_n_dst)
+            # family name = the rocprofv3 row k_conv_ring<cs, cd> (csrc/conv_ring.hip)
+            return t._timed("conv_gemm[mfma %dx%d ring]" % (cs, c_dst), flops, nbytes, sv["conv_gemm_ring"], src, w_packed,
+                            c_dst, kvol, pair, ld, n_dst, plan, flip_k, scale, shift, relu, d_n_dst, perm, want_stats)
+
+        def conv_ring_plan(pair, ld, kvol, n_dst, d_n_dst=None):
+            return t._timed("conv_ring_plan", 0.0, lambda: 4.0 * kvol * t._live(d_n_dst, n_dst), sv["conv_ring_plan"], pair, ld,
+                            kvol, n_dst, d_n_dst)
+
         def conv_plan(pair, ld, kvol, n_dst, d_n_dst=None):
-            return t._timed("conv_plan", 0.0, 4.0 * kvol * n_dst, sv["conv_plan"], pair, ld, kvol, n_dst, d_n_dst)
+            return t._timed("conv_plan", 0.0, lambda: 4.0 * kvol * t._live(d_n_dst, n_dst), sv["conv_plan"], pair, ld, kvol, n_dst,
+                            d_n_dst)
 
         def conv_group(pair, ld, kvol, n_dst, d_n_dst=None):
             # reads the table, writes perm and the grouped table
-            return t._timed("conv_group", 0.0, 4.0 * (2 * kvol + 1) * n_dst, sv["conv_group"], pair, ld, kvol, n_dst, d_n_dst)
+            return t._timed("conv_group", 0.0, lambda: 4.0 * (2 * kvol + 1) * t._live(d_n_dst, n_dst), sv["conv_group"], pair, ld,
+                            kvol, n_dst, d_n_dst)
 
         def conv_wgrad(feat_in, dout, pair, ld, n_out, wshape, d_n_out=None, counts=None):
             cout, cin = wshape[0], wshape[-1]
             K = int(np.prod(wshape[1:-1]))
-            P = t._P(pair, n_out)
-            flops = 2.0 * P * cin * cout
-            nbytes = 4.0 * (feat_in.shape[0] * cin + n_out * cout + K * n_out + K * cin * cout)
+
+            def flops():
+                return 2.0 * t._P(pair, t._live(d_n_out, n_out)) * cin * cout
+
+            def nbytes():
+                no = t._live(d_n_out, n_out)
+                return 4.0 * (feat_in.shape[0] * cin + no * cout + K * no + K * cin * cout)
             # one family per template instantiation (k_wgrad_mfma<cin/16, cout/16, ..>), like the forward kernels
             return t._timed("conv_wgrad[mfma %dx%d]" % (cin, cout), flops, nbytes, sv["conv_wgrad"], feat_in, dout, pair, ld,
                             n_out, wshape, d_n_out, counts)
@@ -230,8 +271,8 @@ class KernelTimer(object):
         def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None):
             n = indices.shape[0]
             K = int(np.prod(ksize))
-            return t._timed("subm_rulebook", 0.0, n * 16.0 + K * n * 4.0, sv["subm_rulebook"], indices, batch_size,
-                            spatial_shape, ksize, dilation, want_cnt, d_n)
+            return t._timed("subm_rulebook", 0.0, lambda: t._live(d_n, n) * (16.0 + K * 4.0), sv["subm_rulebook"], indices,
+                            batch_size, spatial_shape, ksize, dilation, want_cnt, d_n)
 
         def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1),
                           want_cnt=False, **kw):
@@ -240,7 +281,15 @@ class KernelTimer(object):
             rb = sv["conv_rulebook"](indices, batch_size, spatial_shape, ksize, stride, padding, dilation, want_cnt, **kw)
             e1.record()
             n, K = indices.shape[0], int(np.prod(ksize))
-            t.rec.append(("conv_rulebook", 0.0, n * 16.0 + K * rb.n_out * 4.0 + K * n * 4.0 + rb.n_out * 16.0, e0, e1))
+
+            def nbytes():          # live rows on both sides (static capacities: counts stay on the device until now)
+                ni = t._live(kw.get("d_n_in"), n)
+                no = t._live(getattr(rb, "d_n_out", None), rb.n_out)
+                extra = 0.0
+                if getattr(rb, "subm_next", None) is not None:      # the level build also writes the output level's subm table
+                    extra = no * 4.0 * int(np.prod(kw.get("subm_ksize") or (3, 3, 3)))
+                return ni * 16.0 + K * no * 4.0 + K * ni * 4.0 + no * 16.0 + extra
+            t.rec.append(("conv_rulebook", 0.0, nbytes, e0, e1, None))
             return rb
 
         def voxelize(points, *a, **k):
@@ -250,19 +299,22 @@ class KernelTimer(object):
             out = sv["voxelize"](points, *a, **k)
             e1.record()
             c = out["mean"].shape[1] if out["mean"] is not None else 4
-            nv = out["num_voxels"] if out["num_voxels"] is not None else int(out["d_num_voxels"].item())
-            t.rec.append(("voxelize+meanvfe", 0.0, 4.0 * points.shape[0] * c + 4.0 * nv * (c + 4), e0, e1))
+
+            def nbytes():
+                nv = out["num_voxels"] if out["num_voxels"] is not None else int(out["d_num_voxels"].item())
+                return 4.0 * points.shape[0] * c + 4.0 * nv * (c + 4)
+            t.rec.append(("voxelize+meanvfe", 0.0, nbytes, e0, e1, None))
             return out
 
         def densify(features, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
             n, c = features.shape
             cells = batch_size * int(np.prod(spatial_shape))
-            return t._timed("densify(+memset)", 0.0, 4.0 * (n * c + c * cells), sv["densify"], features, indices,
-                            batch_size, spatial_shape, channels_last, d_n)
+            return t._timed("densify(+memset)", 0.0, lambda: 4.0 * (t._live(d_n, n) * c + c * cells), sv["densify"], features,
+                            indices, batch_size, spatial_shape, channels_last, d_n)
 
         def densify_bwd(ddense, indices, batch_size, spatial_shape, channels_last=False, d_n=None):
             n, c = indices.shape[0], ddense.shape[1]
-            return t._timed("densify_bwd", 0.0, 8.0 * n * c, sv["densify_bwd"], ddense, indices, batch_size,
+            return t._timed("densify_bwd", 0.0, lambda: 8.0 * t._live(d_n, n) * c, sv["densify_bwd"], ddense, indices, batch_size,
                             spatial_shape, channels_last, d_n)
 
         def pack_weight(weight, mode):
@@ -297,7 +349,8 @@ class KernelTimer(object):
 
         for n, f in dict(conv2d_wino=conv2d_wino, conv2d_wino_wgrad=conv2d_wino_wgrad, wino_weight=wino_weight).items():
             setattr(ops, n, f)
-        for n, f in dict(conv_gemm=conv_gemm, conv_gemm_balanced=conv_gemm_balanced, conv_plan=conv_plan,
+        for n, f in dict(conv_gemm=conv_gemm, conv_gemm_balanced=conv_gemm_balanced, conv_gemm_ring=conv_gemm_ring,
+                         conv_ring_plan=conv_ring_plan, conv_plan=conv_plan,
                          conv_group=conv_group, conv_wgrad=conv_wgrad, subm_rulebook=subm_rulebook,
                          conv_rulebook=conv_rulebook, voxelize=voxelize, densify=densify, densify_bwd=densify_bwd,
                          pack_weight=pack_weight).items():
@@ -311,7 +364,9 @@ class KernelTimer(object):
     def summary(self, nsteps):
         torch.cuda.synchronize()
         fam = {}
-        for name, fl, by, e0, e1 in self.rec:
+        for name, fl, by, e0, e1, _out in self.rec:
+            fl = fl() if callable(fl) else fl
+            by = by() if callable(by) else by
             d = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, roof_hbm=0.0, roof_mfma=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -322,6 +377,10 @@ class KernelTimer(object):
         for d in fam.values():
             d["ms_per_step"] = d["ms"] / nsteps
             d["launches_per_step"] = d["launches"] / nsteps
+            # fraction of the family's roofline: t_roof = sum over launches of max(bytes / HBM peak, flops / MFMA peak)
+            mf = d["roof_mfma"] >= d["roof_hbm"]
+            d["bound"] = "mfma" if mf else "hbm"
+            d["frac"] = (d["roof_mfma"] if mf else d["roof_hbm"]) / max(d["ms"] * 1e-3, 1e-12)
         return fam
 
 
@@ -349,7 +408,10 @@ def roofline_of(fam):
     else:
         ach, peak, unit, bound = d["bytes"] / t / 1e9, HBM_PEAK / 1e9, "GB/s", "hbm"
     rocprof_name, extra_name = "?", None
-    if name.startswith("conv_gemm[mfma ") and name.endswith(" balanced]"):
+    if name.startswith("conv_gemm[mfma ") and name.endswith(" ring]"):
+        cs, cd = name[len("conv_gemm[mfma "):-len(" ring]")].split("x")
+        rocprof_name = "k_conv_ring<%s, %s>" % (cs, cd)
+    elif name.startswith("conv_gemm[mfma ") and name.endswith(" balanced]"):
         cs, cd = name[len("conv_gemm[mfma "):-len(" balanced]")].split("x")
         rocprof_name = "k_conv_mfma_pbl%s<%s, %s>" % ("2" if cs == "128" else "", cs, cd)   # one kernel since round 2
     elif name.startswith("conv_gemm[mfma "):
@@ -697,15 +759,22 @@ def main():
     torch.cuda.synchronize()
     if caps is not None:
         # a level capacity too small for this data would drop rows: the kernels say so in the device status word.  Then the
-        # run falls back to exact-size tensors (every rank decides alike: ranks see frames of the same generator).
+        # run falls back to exact-size tensors.
         from spx import _lib as _spxlib, ops as _ops0
         for b in batches[args.warmup % len(batches):] + batches[:args.warmup % len(batches)]:
             if args.warmup < len(batches):
                 step(b)                                   # make sure every batch of the timed loop has been seen once
-        try:
-            _ops0.check_status(device)
-        except _spxlib.SpxError as e:
-            sys.stderr.write("bench.py: %s -> falling back to exact-size tensors\n" % e)
+        # Ranks see DIFFERENT frames (make_batches seeds by rank), so one rank alone may overflow: the decision is taken by all
+        # of them together — MIN over ranks of the status word (error codes are negative) — or the rank that fell back would
+        # issue DDP steps (gradient all-reduces) the others never join.
+        word = _ops0.status_word(device).clone()
+        if world > 1:
+            dist.all_reduce(word, op=dist.ReduceOp.MIN)
+        rc = int(word.item())
+        _ops0.status_word(device).zero_()
+        if rc != 0:
+            sys.stderr.write("bench.py: device status %d (%s) on some rank -> every rank falls back to exact-size tensors\n"
+                             % (rc, _spxlib.load().spx_strerror(rc).decode()))
             caps = None
             step.static_caps = None
             step.graphed = None
@@ -760,10 +829,14 @@ def main():
     if not args.no_roofline:
         kt = KernelTimer()
         kt.install()
-        # algorithmic FLOPs / bytes need exact row counts on the host: the instrumented steps run the exact-size path (the
-        # same kernels; at static capacity their grids only carry extra blocks that exit at once)
-        step.static_caps = None
+        # The instrumented steps run the SAME execution mode as the timed ones (static capacities: no host read inside the step,
+        # so an event pair holds kernel time only — round 2 ran them on the exact-size path and timed host waits into the
+        # index families); the algorithmic FLOPs / bytes are computed from the device-side live counts after each launch has
+        # been timed.  Only the hipGraph replay is switched off (it has no per-kernel events) ...
         step.graphed = None
+        # ... and every stream is folded into the launch stream: the rule tables normally run on a second stream
+        import spx.prebuild as _pb
+        _side_saved, _pb.side_stream = _pb.side_stream, (lambda dev: torch.cuda.current_stream(dev))
         # ... and every kernel in stream order: in the timed steps the weight-gradient kernels run on a second stream beside
         # whatever the main stream is doing (spx/functional.py: _off_critical_path), which stretches the kernels they share
         # the chip with; an event pair around a launch would then time the overlap, not the kernel
@@ -775,11 +848,13 @@ def main():
         fam = kt.summary(n_inst)
         kt.uninstall()
         _fn._ASYNC_WGRAD = _async
+        _pb.side_stream = _side_saved
         if rank == 0:
             line["roofline"] = roofline_of(fam)
             line["kernels"] = {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"],
                                    "GFLOP_per_step": round(v["flops"] / n_inst / 1e9, 3),
-                                   "MB_per_step": round(v["bytes"] / n_inst / 1e6, 3)} for k, v in fam.items()}
+                                   "MB_per_step": round(v["bytes"] / n_inst / 1e6, 3),
+                                   "bound": v["bound"], "frac": round(v["frac"], 4)} for k, v in fam.items()}
             if args.breakdown:
                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
                     sys.stderr.write("%-22s %7.3f ms/step  %5.1f launches  %8.2f GFLOP  %8.2f MB  -> %6.2f TFLOP/s %7.1f GB/s\n"
