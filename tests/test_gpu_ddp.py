@@ -22,15 +22,21 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _model_and_data():
+def _model_and_data(freeze_bn=False):
     from pcdet_amd.config import AttrDict, cfg_from_yaml_file
     from pcdet_amd.datasets import SyntheticDataset
     from pcdet_amd.models import build_network
     cfg = cfg_from_yaml_file(os.path.join(ROOT, "tsm-det-pointcloud-_amd/tools/cfgs/kitti_models/second.yaml"), AttrDict())
     ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, True, cfg_id=0, length=4)
     torch.manual_seed(0)
-    model = build_network(cfg.MODEL, 3, ds)
-    return ds, model.train()
+    model = build_network(cfg.MODEL, 3, ds).train()
+    if freeze_bn:                  # BatchNorm on its running statistics: no batch-statistics feedback, per-parameter bars apply
+        g = torch.Generator().manual_seed(1)
+        for m in model.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.eval()
+    return ds, model
 
 
 def _batch(ds, fid, dev, static, model):
@@ -43,14 +49,14 @@ def _batch(ds, fid, dev, static, model):
     return bd
 
 
-def _worker(rank, world, port, out_dir, static):
+def _worker(rank, world, port, out_dir, static, freeze_bn=False):
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     from spx import ops
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
-    ds, model = _model_and_data()
+    ds, model = _model_and_data(freeze_bn)
     model.to(dev)
     ddp = torch.nn.parallel.DistributedDataParallel(model, bucket_cap_mb=8, gradient_as_bucket_view=True)
     ret, _tb, _ = ddp(_batch(ds, rank, dev, static, model))      # rank r trains on frame r (DistributedSampler-style)
@@ -62,10 +68,10 @@ def _worker(rank, world, port, out_dir, static):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("static", [False, True])
-def test_ddp_two_ranks_on_the_hip_path(tmp_path, static):
-    world, port = 2, 29600 + (os.getpid() % 2000) + (7 if static else 0)
-    mp.spawn(_worker, args=(world, port, str(tmp_path), static), nprocs=world, join=True)
+@pytest.mark.parametrize("static,freeze_bn", [(False, False), (True, False), (True, True)])
+def test_ddp_two_ranks_on_the_hip_path(tmp_path, static, freeze_bn):
+    world, port = 2, 29600 + (os.getpid() % 2000) + (7 if static else 0) + (13 if freeze_bn else 0)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), static, freeze_bn), nprocs=world, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=True)
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=True)
     for n in r0["grads"]:                       # after the all-reduce every rank holds the same (averaged) gradients
@@ -76,7 +82,7 @@ def test_ddp_two_ranks_on_the_hip_path(tmp_path, static):
     dev = torch.device("cuda:0")
     singles = []
     for fid in (0, 1):
-        ds, model = _model_and_data()
+        ds, model = _model_and_data(freeze_bn)
         model.to(dev)
         ret, _tb, _ = model(_batch(ds, fid, dev, static, model))
         ret["loss"].backward()
@@ -95,3 +101,12 @@ def test_ddp_two_ranks_on_the_hip_path(tmp_path, static):
         errs.append((float((r0["grads"][n] - want).abs().max() / want.abs().max().clamp_min(1e-12)), n))
     errs.sort(reverse=True)
     assert (num / den) ** 0.5 < 2e-2, ((num / den) ** 0.5, errs[:6])
+    if freeze_bn:
+        # frozen BatchNorm: nothing amplifies round-off, so the averaged gradients must match PER PARAMETER (relative L2)
+        worst = ("", 0.0)
+        for n in singles[0]:
+            want = 0.5 * (singles[0][n] + singles[1][n]).double()
+            r = float(((r0["grads"][n].double() - want) ** 2).sum() / (want ** 2).sum().clamp_min(1e-30)) ** 0.5
+            if r > worst[1]:
+                worst = (n, r)
+        assert worst[1] < 2e-3, worst

@@ -280,3 +280,73 @@ def test_conv_bn_relu_node_takes_statistics_in_the_conv_epilogue():
     _check(conv.weight.grad, conv64.weight.grad, tol=1e-4)
     _check(bn.weight.grad, bn64.weight.grad, tol=1e-4)
     _check(bn.bias.grad, bn64.bias.grad, tol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ full BASELINE sizes, float64 on the GPU
+
+def _taps64(x):
+    """x [N, C, H, W] -> the nine zero-padded shifted views of x as float64 channels-last rows [9][N*H*W, C] (on the GPU)."""
+    n, c, h, w = x.shape
+    xp = F.pad(x.double().permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))               # [N, H+2, W+2, C]
+    return [xp[:, a:a + h, b:b + w, :].reshape(n * h * w, c) for a in range(3) for b in range(3)]
+
+
+def _conv64(x, wt):
+    """float64 conv2d(x, wt, padding=1) as nine GEMMs on the GPU -> [N*H*W, Cout] rows."""
+    w64 = wt.double()
+    y = None
+    for t, rows in enumerate(_taps64(x)):
+        a, b = divmod(t, 3)
+        part = rows @ w64[:, :, a, b].t()
+        y = part if y is None else y + part
+    return y
+
+
+def _rows(t):
+    n, c, h, w = t.shape
+    return t.permute(0, 2, 3, 1).reshape(n * h * w, c)
+
+
+def _bar(got, ref, tol):
+    err = float((got.double() - ref).abs().max())
+    scale = max(1.0, float(ref.abs().max()))
+    assert err <= tol * scale, "max|err| %.3e > %.1e * %.3g" % (err, tol, scale)
+    return err / scale
+
+
+@pytest.mark.parametrize("n,c,h,w", [(4, 128, 200, 176), (4, 256, 100, 88), (2, 128, 188, 188), (2, 256, 94, 94),
+                                      (3, 128, 101, 77)])
+def test_full_size_forward_dgrad_wgrad_and_bn_sums_against_float64(n, c, h, w):
+    """The BEV layers of BASELINE configs[1] (KITTI: 4 x 128 x 200 x 176, 4 x 256 x 100 x 88) and configs[2] (Waymo:
+    2 x 128 x 188 x 188, 2 x 256 x 94 x 94) at FULL size, plus an odd map (the last XCD range of tile blocks and the last
+    weight-gradient split partly empty): forward, data gradient, weight gradient (its split ranges only exist at these
+    sizes) and the BatchNorm sums of the forward's epilogue, each against float64 computed on the GPU as nine GEMMs.
+    Reference: pcdet/models/backbones_2d/base_bev_backbone.py:38-49."""
+    from spx import ops
+    g = torch.Generator().manual_seed(n * 1000 + h)
+    dev = torch.device("cuda:0")
+    x = torch.randn((n, c, h, w), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((n, c, h, w), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn((c, c, 3, 3), generator=g) / np.sqrt(9 * c)).to(dev)
+    # forward + epilogue sums
+    y, part = ops.conv2d_wino(x, ops.wino_weight(wt), c, stats=True)
+    ref = _conv64(x, wt)
+    e_f = _bar(_rows(y), ref, TOL)
+    s = part.double().sum(0)
+    assert float((s[0] - ref.sum(0)).abs().max()) <= 2e-5 * float(ref.abs().sum(0).max())
+    assert float((s[1] - (ref * ref).sum(0)).abs().max()) <= 2e-5 * float((ref * ref).sum(0).max())
+    del ref
+    # data gradient = conv of dy with the rotated, transposed filter
+    dx = ops.conv2d_wino(dy, ops.wino_weight(wt, flip=True), c)
+    wflip = wt.flip(2, 3).transpose(0, 1).contiguous()
+    e_d = _bar(_rows(dx), _conv64(dy, wflip), TOL)
+    # weight gradient: dw[co, ci, a, b] = sum_pixels dy[p, co] * x[p shifted by (a, b), ci]
+    dw = ops.conv2d_wino_wgrad(x, dy, wt)
+    dy64 = _rows(dy).double()
+    want = torch.empty((c, c, 3, 3), dtype=torch.float64, device=dev)
+    for t, rows in enumerate(_taps64(x)):
+        a, b = divmod(t, 3)
+        want[:, :, a, b] = dy64.t() @ rows
+    e_w = _bar(dw, want, 5e-5)
+    assert torch.equal(dw, ops.conv2d_wino_wgrad(x, dy, wt))             # fixed summation order
+    print("rel err fwd %.2e dgrad %.2e wgrad %.2e" % (e_f, e_d, e_w))

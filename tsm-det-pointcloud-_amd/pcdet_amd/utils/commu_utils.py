@@ -47,12 +47,16 @@ def average_reduce_value(data):
 
 
 def all_reduce(data, op="sum", average=False):
-    """in-place all-reduce of a tensor; op in sum / max / min / product."""
-    if get_world_size() == 1:
+    """All-reduce of a tensor over the ranks; op in sum / max / min / product.  As the reference's helper
+    (pcdet/utils/commu_utils.py:148-168) the argument is NOT modified: the reduction runs on a clone and, with average=True,
+    a new tensor reduced / world_size is returned (so integer tensors average to floats instead of raising)."""
+    world = get_world_size()
+    if world == 1:
         return data
     ops = {"SUM": dist.ReduceOp.SUM, "MAX": dist.ReduceOp.MAX, "MIN": dist.ReduceOp.MIN, "PRODUCT": dist.ReduceOp.PRODUCT}
-    dist.all_reduce(data, op=ops[op.upper()])
+    reduced = data.clone()
+    dist.all_reduce(reduced, op=ops[op.upper()])
     if average:
         assert op.upper() == "SUM"
-        data /= get_world_size()
-    return data
+        return reduced / world
+    return reduced

@@ -4,6 +4,7 @@ Replaces the autograd behaviour of spconv.pytorch convolutions / .dense() that t
 loss.backward() (tools/train_utils/train_utils.py:53).
 """
 import os
+import weakref
 
 import torch
 
@@ -46,7 +47,7 @@ def _packed(weight, mode):
     return wp
 
 
-_BANKS = {}
+_BANKS = weakref.WeakKeyDictionary()       # first conv module of a stack -> its PackedBank: released with the model
 
 
 def pack_all(convs):
@@ -66,7 +67,7 @@ def pack_all(convs):
             break
     if not stale:
         return False
-    key = id(convs[0])
+    key = convs[0]
     bank = _BANKS.get(key)
     if bank is None or not bank.valid_for(ws):
         bank = _BANKS[key] = ops.PackedBank(ws)
@@ -91,6 +92,9 @@ def _side_stream(device):
     return s
 
 
+_DEFERRED = set()          # id() of the weights whose gradient join was deferred in the running backward pass
+
+
 def _join_after_backward(main, side, keep):
     """main waits for side when the running backward pass has finished (autograd engine callback, as DDP does for its
     buckets): whatever runs on `main` after loss.backward() — gradient clipping, the optimizer — sees the finished gradients.
@@ -101,6 +105,7 @@ def _join_after_backward(main, side, keep):
     def _join():
         main.wait_stream(side)
         keep.clear()
+        _DEFERRED.clear()
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
@@ -119,10 +124,16 @@ def _off_critical_path(fn, reads, weight):
     with torch.cuda.stream(side):
         g = fn()
     g.record_stream(main)           # allocated in the side stream's pool, consumed (optimizer) and freed on the main stream
-    if _nobody_reads_before_the_optimizer(weight):
+    # Deferring the join is only safe while AccumulateGrad STORES the tensor as it is (no kernel): a leaf without .grad and
+    # hooks (see below), a gradient in the parameter's own layout (else the engine copies it into that layout on the main
+    # stream), and the FIRST gradient of this weight in this pass — a weight used by two conv nodes gets its two gradients
+    # summed by the engine's input buffer on the main stream as soon as the second one arrives.
+    if (_nobody_reads_before_the_optimizer(weight) and id(weight) not in _DEFERRED
+            and tuple(g.shape) == tuple(weight.shape) and g.stride() == weight.stride()):
+        _DEFERRED.add(id(weight))
         _join_after_backward(main, side, list(reads))
     else:
-        main.wait_stream(side)      # from here on stream order protects `reads`
+        main.wait_stream(side)      # from here on stream order protects `reads` (and every earlier side-stream gradient)
     return g
 
 
@@ -405,7 +416,19 @@ def bn_act(x, bn, relu, residual=None, d_n=None):
     if bn_train_fusable(bn, x):
         return bn_relu_train(x, bn, relu, residual, d_n)
     if d_n is not None:
-        raise RuntimeError("static-capacity rows need the fused BatchNorm kernels (training mode on the GPU, fp32)")
+        if bn.training or bn.running_mean is None:
+            raise RuntimeError("static-capacity rows need the fused BatchNorm kernels (training mode on the GPU, fp32) or a "
+                               "BatchNorm on its running statistics")
+        # BatchNorm on its running statistics while the model trains (frozen BatchNorm): row-local torch modules with the rows
+        # beyond the live count (garbage, possibly NaN, and so is their gradient) replaced by zeros before and after — selects,
+        # not multiplies — so that neither the output nor the parameter gradients (sums over rows) see them
+        live = (torch.arange(x.shape[0], device=x.device) < d_n).unsqueeze(1)
+        zero = torch.zeros((), dtype=x.dtype, device=x.device)
+        y = bn(torch.where(live, x, zero))
+        if residual is not None:
+            y = y + torch.where(live, residual, zero)
+        y = torch.relu(y) if relu else y
+        return torch.where(live, y, zero)
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -418,13 +441,17 @@ def _wino_image(weight, flip):
     """Transformed weight image of `weight` (flip: of its data-gradient filter), in a buffer that lives ON the weight tensor
     (attribute) and is re-filled when the weight has changed: once per call in training (the optimizer steps in between;
     ~10 us), once in all at inference.  One persistent buffer per layer and direction — no allocation per call."""
+    # Capture FIRST, as _packed does: a graph must record the transform kernel into a buffer of its own.  (Round 2 looked at
+    # the cache first: GraphedTrainStep warms up without an optimizer step, so the forward of every BEV conv hit the cache,
+    # no spx_wino_weight was recorded, and every replay after the first optimizer.step() convolved with the weights of capture
+    # time while dgrad / wgrad used the current ones.)
+    if weight.is_cuda and torch.cuda.is_current_stream_capturing():
+        return ops.wino_weight(weight, flip)            # a captured graph owns its buffers
     attr = '_spx_wino_flip' if flip else '_spx_wino'
     hit = getattr(weight, attr, None)
     fresh = hit is not None and hit[1] == weight.data_ptr() and hit[2].device == weight.device
     if fresh and hit[0] == weight._version and not (torch.is_grad_enabled() and weight.requires_grad):
         return hit[2]
-    if torch.cuda.is_current_stream_capturing():
-        return ops.wino_weight(weight, flip)            # a captured graph owns its buffers
     u = ops.wino_weight(weight, flip, out=hit[2] if fresh else None)
     setattr(weight, attr, (weight._version, weight.data_ptr(), u))
     return u

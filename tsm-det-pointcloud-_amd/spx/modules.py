@@ -98,14 +98,37 @@ class SparseSequential(SparseModule):
                     continue
             elif isinstance(input, SparseConvTensor):
                 if input.n_valid is not None:
-                    raise RuntimeError("static-capacity tensors carry garbage rows beyond n_valid: only sparse modules "
-                                       "and their fused BatchNorm/ReLU epilogue (eval + no_grad) may touch them")
+                    if _row_local(module):
+                        # e.g. BatchNorm1d on its running statistics while the model trains (frozen BatchNorm, fine-tuning)
+                        input = _on_live_rows(module, input)
+                        i += 1
+                        continue
+                    raise RuntimeError("static-capacity tensors carry garbage rows beyond n_valid: only sparse modules, "
+                                       "their fused BatchNorm/ReLU and row-local modules (eval BatchNorm1d, ReLU) may "
+                                       "touch them")
                 if input.indices.shape[0] != 0:
                     input = input.replace_feature(module(input.features))
             else:
                 input = module(input)
             i += 1
         return input
+
+
+def _row_local(module):
+    """Modules whose output row depends on the same input row only (and on no batch statistic)."""
+    return isinstance(module, (nn.ReLU, nn.Identity)) or (isinstance(module, nn.BatchNorm1d) and not module.training
+                                                          and module.running_mean is not None)
+
+
+def _on_live_rows(module, x):
+    """A row-local torch module on a static-capacity tensor.  Rows beyond n_valid hold whatever the buffer held (possibly
+    NaN) and so do the rows of the gradient that comes back: both are replaced by zeros around the module — a select, not
+    a multiply — so that neither the module's output nor its parameter gradients (sums over rows) ever see them."""
+    f = x.features
+    live = (torch.arange(f.shape[0], device=f.device) < x.n_valid).unsqueeze(1)
+    zero = torch.zeros((), dtype=f.dtype, device=f.device)
+    y = module(torch.where(live, f, zero))
+    return x.replace_feature(torch.where(live, y, zero))
 
 
 _FUSED_BLOCK = os.environ.get("SPX_FUSED_BLOCK", "1") != "0"     # dev knob: conv and BN+ReLU as separate autograd nodes
