@@ -382,8 +382,11 @@ int spx_bn_apply(const float *x, const float *res, int64_t n, const int64_t *d_n
 
 /* Training-mode BatchNorm (+ReLU) from per-block sums taken by the producer of x (spx_conv2d_wino's stat_partials):
  * partial[nblk][2][c] = sums of x and x*x; finalize + apply, no statistics pass over x.  replaces: the same nn.BatchNorm2d
- * (train) + nn.ReLU as spx_bn_add_relu_fwd for the 3x3 layers of the BEV backbone, base_bev_backbone.py:38-49. */
-int spx_bn_relu_fwd_from_sums(const float *x, int64_t n, int c, const float *partial, int64_t nblk, const float *gamma,
+ * (train) + nn.ReLU as spx_bn_add_relu_fwd for the 3x3 layers of the BEV backbone, base_bev_backbone.py:38-49, and (with the
+ * sums of spx_conv_gemm_ring's epilogue) the nn.BatchNorm1d + nn.ReLU of the 64-channel sparse blocks,
+ * spconv_backbone.py:26-27,81.  d_n (nullable): device-side live row count of a static-capacity row matrix. */
+int spx_bn_relu_fwd_from_sums(const float *x, int64_t n, const int64_t *d_n, int c, const float *partial, int64_t nblk,
+                              const float *gamma,
                               const float *beta, float *running_mean, float *running_var, int64_t *num_batches_tracked,
                               float momentum, float eps, int relu, float *y, int64_t y_ld, float *save_mean,
                               float *save_invstd, spx_stream_t stream);

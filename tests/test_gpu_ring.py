@@ -53,8 +53,7 @@ def _check_plan(ops, plan, pair, ld, K, n, live):
     assert plan.numel() * 4 == nbytes
     tcap = (n + 15) // 16 + 1
     kHdr = 32 + 8 * 96
-    off_pre = kHdr + (tcap + 3) // 4 * 4
-    off_sorted = off_pre + (tcap + 1 + 3) // 4 * 4
+    off_sorted = kHdr + (tcap + 3) // 4 * 4
     off_ent = off_sorted + (tcap + 3) // 4 * 4
     R = max(hdr["rounds"])
     ent = plan[off_ent: off_ent + R * 256 * 12 * 2].view(R, 256, 12, 2).cpu()

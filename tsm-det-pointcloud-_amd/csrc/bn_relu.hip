@@ -257,7 +257,7 @@ extern "C" int spx_bn_add_relu_fwd(const float* x, const float* res, int64_t n, 
 // Training-mode BatchNorm (+ReLU) whose per-channel sums were already taken by the PRODUCER of x — csrc/wino_conv2d.hip
 // writes, per block of 32 output tiles, the sums of y and y*y it stores (partial[nblk][2][C]) — so the statistics pass over x
 // is skipped: finalize (fp64 combine of the rows, running statistics) + apply.
-extern "C" int spx_bn_relu_fwd_from_sums(const float* x, int64_t n, int c, const float* partial, int64_t nblk,
+extern "C" int spx_bn_relu_fwd_from_sums(const float* x, int64_t n, const int64_t* d_n, int c, const float* partial, int64_t nblk,
                                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                                          int64_t* num_batches_tracked, float momentum, float eps, int relu, float* y,
                                          int64_t y_ld, float* save_mean, float* save_invstd, spx_stream_t stream) {
@@ -269,9 +269,9 @@ extern "C" int spx_bn_relu_fwd_from_sums(const float* x, int64_t n, int c, const
   if (y_ld < c || y_ld % 4 != 0 || ((uintptr_t)y & 15) != 0) return SPX_ERR_INVALID_ARG;
   hipStream_t s = spx_s(stream);
   const int cshift = log2_of(c);
-  hipLaunchKernelGGL(k_bn_finalize, dim3(c), dim3(64), 0, s, partial, (int)nblk, c, n, nullptr, eps, momentum, save_mean,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(c), dim3(64), 0, s, partial, (int)nblk, c, n, d_n, eps, momentum, save_mean,
                      save_invstd, running_mean, running_var, num_batches_tracked);
-  hipLaunchKernelGGL(k_bn_apply, dim3(bn_blocks(n, c)), dim3(256), 0, s, x, save_mean, save_invstd, gamma, beta, n, nullptr, c,
+  hipLaunchKernelGGL(k_bn_apply, dim3(bn_blocks(n, c)), dim3(256), 0, s, x, save_mean, save_invstd, gamma, beta, n, d_n, c,
                      relu, nullptr, y_ld, cshift, y);
   SPX_CHECK_LAUNCH();
   return SPX_OK;

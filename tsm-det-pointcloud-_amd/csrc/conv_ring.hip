@@ -71,14 +71,13 @@ __host__ __device__ inline int ring_chunks(int64_t nlive) {
 __host__ __device__ inline int chunk_begin(int c, int T, int W) { return (int)((int64_t)c * T / W); }
 constexpr int kSpinLimit = 1 << 18;        // ~30 ms of polling: a protocol bug ends as plan[2] != 0, never as a hang
 
-// plan layout (int32): hdr[kHdr] | mask[tcap] | pre[tcap + 1] | sorted[tcap] | ent[rcap][kRG][kCW][kTM][2]
+// plan layout (int32): hdr[kHdr] | mask[tcap] | sorted[tcap] | ent[rcap][kRG][kCW][kTM][2]
 __host__ __device__ inline int64_t ring_tcap(int64_t n) { return (n + 15) / 16 + 1; }
 // rounds an XCD can need: it holds NC / 8 chunks of at most ceil(T / NC) tiles each
 __host__ __device__ inline int64_t ring_rcap(int64_t tcap) { return ((tcap + 7) / 8 + kMaxCh + kPerRound - 1) / kPerRound + 1; }
 constexpr int64_t kMaxRows = (int64_t)60 * kPerRound * 8 * 16;   // rounds <= 64: a wave keeps its tiles on its 64 lanes (2.9 M rows)
 __host__ __device__ inline int64_t off_mask() { return kHdr; }
-__host__ __device__ inline int64_t off_pre(int64_t tcap) { return off_mask() + (tcap + 3) / 4 * 4; }
-__host__ __device__ inline int64_t off_sorted(int64_t tcap) { return off_pre(tcap) + (tcap + 1 + 3) / 4 * 4; }
+__host__ __device__ inline int64_t off_sorted(int64_t tcap) { return off_mask() + (tcap + 3) / 4 * 4; }
 __host__ __device__ inline int64_t off_ent(int64_t tcap) { return off_sorted(tcap) + (tcap + 3) / 4 * 4; }
 __host__ __device__ inline int64_t plan_ints(int64_t tcap) {
   return off_ent(tcap) + ring_rcap(tcap) * (int64_t)kRG * kCW * kTM * 2;
@@ -107,66 +106,57 @@ __global__ __launch_bounds__(256) void k_ring_mask(const int32_t* __restrict__ p
   if (r == 0 && tile < tcap) plan[off_mask() + tile] = tile < T ? (int32_t)m : 0;
 }
 
-// ---------------------------------------------------------------- plan 2 (one block): weights prefix, range bounds
-// weight of a tile = its non-empty offsets + 1 (the epilogue); ranges = eight contiguous pieces of equal weight
-__global__ __launch_bounds__(1024) void k_ring_scan(int64_t n, const int64_t* d_n, int64_t tcap, int32_t* __restrict__ plan) {
-  __shared__ int s_wave[16];
-  __shared__ int s_carry;
+// ---------------------------------------------------------------- plan 2 (one block per XCD): chunks -> XCDs, order, deal
+// Chunks -> XCDs.  Eight contiguous ranges of equal weight (weight of a tile = its non-empty offsets + 1 for the epilogue) need
+// very different tile counts (ground planes are heavy, upper levels light), and a range over its share of tiles costs its
+// workgroups a whole extra turn of the ring; contiguous ranges of equal tile count differ by 20 % in weight.  So: NC / 8 whole
+// chunks per XCD (equal tile counts, each chunk a compact piece of the row order: the XCD's L2 holds those pieces), chosen
+// greedily by weight, heaviest chunk first to the XCD that carries the least.  Every block computes this (tiny, deterministic)
+// assignment for itself from the masks — no separate launch, no prefix array.
+__global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* d_n, int64_t tcap, int K,
+                                                      int32_t* __restrict__ plan) {
+  __shared__ int s_hist[32];
+  __shared__ int s_start[32];
+  __shared__ int s_wcnt[16][32];
+  __shared__ int s_cw[8 * kMaxCh];         // chunk weights
+  __shared__ int s_ord[8 * kMaxCh];        // chunks by descending weight
+  __shared__ int s_xof[8 * kMaxCh];        // chunk -> XCD
+  __shared__ int s_units;
+  __shared__ int s_cpre[kMaxCh + 1];
+  __shared__ int s_cbeg[kMaxCh];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int x = blockIdx.x;
   const int64_t nlive = spx_live_n(d_n, n);
   const int T = (int)((nlive + 15) / 16);
-  const int32_t* mask = plan + off_mask();
-  int32_t* pre = plan + off_pre(tcap);
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  int units = 0;
-  for (int base = 0; base < T; base += 1024) {
-    const int S = base + tid;
-    const int pc = S < T ? __popc((unsigned)mask[S]) : 0;
-    const int v = S < T ? pc + 1 : 0;
-    units += pc;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_wave[wv] = incl;
-    __syncthreads();
-    int off = s_carry;
-    for (int i = 0; i < wv; ++i) off += s_wave[i];
-    if (S < T) pre[S] = off + incl - v;
-    __syncthreads();
-    if (tid == 1023) s_carry = off + incl;
-    __syncthreads();
-  }
-  const int W = s_carry;
-  // total units (header only)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) units += __shfl_xor(units, o);
-  if (lane == 0) s_wave[wv] = units;
-  __syncthreads();
   const int NC = ring_chunks(nlive);
-  if (tid == 0) {
-    int u = 0;
-    for (int i = 0; i < 16; ++i) u += s_wave[i];
-    pre[T] = W;
+  const int32_t* mask = plan + off_mask();
+  int32_t* sorted = plan + off_sorted(tcap);
+  int32_t* ent = plan + off_ent(tcap);
+  for (int c = tid; c < NC; c += 1024) s_cw[c] = 0;
+  if (tid == 0) s_units = 0;
+  if (tid < 32) s_hist[tid] = 0;
+  __syncthreads();
+  {
+    int units = 0;
+    for (int t = tid; t < T; t += 1024) {
+      const int pc = __popc((unsigned)mask[t]);
+      units += pc;
+      int c = (int)((int64_t)t * NC / T);
+      while (c + 1 < NC && chunk_begin(c + 1, T, NC) <= t) ++c;
+      while (c > 0 && chunk_begin(c, T, NC) > t) --c;
+      atomicAdd(&s_cw[c], pc + 1);                      // integer sums: order-free
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) units += __shfl_xor(units, o);
+    if (lane == 0) atomicAdd(&s_units, units);
+  }
+  __syncthreads();
+  if (x == 0 && tid == 0) {
     plan[0] = T;
-    plan[1] = u;
+    plan[1] = s_units;
     plan[2] = 0;
     plan[3] = NC;
   }
-  __threadfence_block();
-  __syncthreads();
-  // Chunks -> XCDs.  Eight contiguous ranges of equal weight need very different tile counts (ground planes are heavy, upper
-  // levels light), and a range over its share of tiles costs its workgroups a whole extra turn of the ring; contiguous ranges
-  // of equal tile count differ by 20 % in weight.  So: NC / 8 whole chunks per XCD (equal tile counts, each chunk a compact
-  // piece of the row order: the XCD's L2 holds those pieces), chosen greedily by weight, heaviest chunk first to the XCD that
-  // carries the least.
-  __shared__ int s_cw[8 * kMaxCh];
-  __shared__ int s_ord[8 * kMaxCh];
-  for (int c = tid; c < NC; c += 1024) s_cw[c] = pre[chunk_begin(c + 1, T, NC)] - pre[chunk_begin(c, T, NC)];
-  __syncthreads();
   for (int c = tid; c < NC; c += 1024) {
     const int my = s_cw[c];
     int rank = 0;
@@ -179,66 +169,48 @@ __global__ __launch_bounds__(1024) void k_ring_scan(int64_t n, const int64_t* d_
   __syncthreads();
   if (tid == 0) {
     int load[8], cnt[8];
-    for (int x = 0; x < 8; ++x) load[x] = 0, cnt[x] = 0;
+    for (int xx = 0; xx < 8; ++xx) load[xx] = 0, cnt[xx] = 0;
     const int each = NC / 8;
     for (int i = 0; i < NC; ++i) {
       const int c = s_ord[i];
       int best = -1;
-      for (int x = 0; x < 8; ++x)
-        if (cnt[x] < each && (best < 0 || load[x] < load[best])) best = x;
-      plan[32 + best * kMaxCh + cnt[best]] = c;
+      for (int xx = 0; xx < 8; ++xx)
+        if (cnt[xx] < each && (best < 0 || load[xx] < load[best])) best = xx;
+      s_xof[c] = best;
       cnt[best] += 1;
       load[best] += s_cw[c];
     }
-    int base = 0;
-    for (int x = 0; x < 8; ++x) {
-      plan[16 + x] = cnt[x];
-      plan[24 + x] = base;
-      for (int j = 0; j < cnt[x]; ++j) {
-        const int c = plan[32 + x * kMaxCh + j];
-        base += chunk_begin(c + 1, T, NC) - chunk_begin(c, T, NC);
+    // this XCD's tiles: its chunks in chunk order (ascending rows), one after the other; local position i -> tile
+    int run = 0, j = 0, base = 0;
+    for (int c = 0; c < NC; ++c) {
+      const int sz = chunk_begin(c + 1, T, NC) - chunk_begin(c, T, NC);
+      if (s_xof[c] < x) base += sz;
+      if (s_xof[c] == x) {
+        s_cpre[j] = run;
+        s_cbeg[j] = chunk_begin(c, T, NC);
+        plan[32 + x * kMaxCh + j] = c;
+        run += sz;
+        ++j;
       }
     }
-  }
-}
-
-// ---------------------------------------------------------------- plan 3 (one block per range): order by units, level deal
-__global__ __launch_bounds__(1024) void k_ring_assign(int64_t tcap, int K, int32_t* __restrict__ plan) {
-  __shared__ int s_hist[32];
-  __shared__ int s_start[32];
-  __shared__ int s_wcnt[16][32];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int x = blockIdx.x;
-  const int T = plan[0], NC = plan[3];
-  // this XCD's tiles: its chunks one after the other; local position i -> tile
-  __shared__ int s_cpre[kMaxCh + 1];
-  __shared__ int s_cbeg[kMaxCh];
-  const int nch = plan[16 + x];
-  if (tid == 0) {
-    int run = 0;
-    for (int j = 0; j < nch; ++j) {
-      const int c = plan[32 + x * kMaxCh + j];
-      s_cpre[j] = run;
-      s_cbeg[j] = chunk_begin(c, T, NC);
-      run += chunk_begin(c + 1, T, NC) - chunk_begin(c, T, NC);
-    }
-    s_cpre[nch] = run;
+    s_cpre[j] = run;
+    plan[16 + x] = j;
+    plan[24 + x] = base;
+    s_start[0] = j;                                     // hand nch / base to the block through LDS
+    s_start[1] = base;
   }
   __syncthreads();
+  const int nch = s_start[0];
+  const int a = s_start[1];                             // this XCD's piece of `sorted`
   const int nx = s_cpre[nch];
+  __syncthreads();
   auto tile_at = [&](int i) -> int {
     int j = 0;
     while (j + 1 < nch && s_cpre[j + 1] <= i) ++j;
     return s_cbeg[j] + (i - s_cpre[j]);
   };
-  const int a = plan[24 + x];                           // this XCD's piece of `sorted`
-  const int32_t* mask = plan + off_mask();
-  int32_t* sorted = plan + off_sorted(tcap);
-  int32_t* ent = plan + off_ent(tcap);
   const int rounds = (nx + kPerRound - 1) / kPerRound;
   if (tid == 0) plan[8 + x] = rounds;
-  if (tid < 32) s_hist[tid] = 0;
-  __syncthreads();
   for (int i = tid; i < nx; i += 1024) atomicAdd(&s_hist[__popc((unsigned)mask[tile_at(i)])], 1);   // integer counts: order-free
   __syncthreads();
   if (tid == 0) {                     // heaviest first
@@ -283,8 +255,16 @@ __global__ __launch_bounds__(1024) void k_ring_assign(int64_t tcap, int K, int32
   // SIMD).  Row `h` of a round goes to wave simd + 4 * h.
   __shared__ int s_load[kBins];
   __shared__ int s_binof[kBins];
+  __shared__ int s_rt[kDealRows * kBins];  // the round's tiles (sorted order) and their masks: two dependent global reads
+  __shared__ int s_rm[kDealRows * kBins];  // once per round instead of once per row
   for (int rd = 0; rd < rounds; ++rd) {
     if (tid < kBins) s_load[tid] = 0;
+    if (tid < kPerRound) {
+      const int p = rd * kPerRound + tid;
+      const int tile = p < nx ? sorted[a + p] : -1;
+      s_rt[tid] = tile;
+      s_rm[tid] = tile >= 0 ? mask[tile] : 0;
+    }
     __syncthreads();
     // rows of this round; a last row that does not fill every bin is placed FIRST (its tiles are the round's lightest): the
     // bins that end up with one tile more than the others must get lighter tiles from the full rows, and a greedy deal can
@@ -294,26 +274,28 @@ __global__ __launch_bounds__(1024) void k_ring_assign(int64_t tcap, int K, int32
     const bool partial = left < kPerRound && (left % kBins) != 0;
     for (int step = 0; step < nrows; ++step) {
       const int row = partial ? (step == 0 ? nrows - 1 : step - 1) : step;
-      const int base = rd * kPerRound + row * kBins;
-      if (tid < kBins) {
-        const int my = s_load[tid];
+      {
+        const int bin = tid >> 3, part = tid & 7;        // eight threads per bin, sixteen comparisons each
+        const int my = s_load[bin];
         int rank = 0;
-        for (int o = 0; o < kBins; ++o) {
+        for (int o = 16 * part; o < 16 * part + 16; ++o) {
           const int v = s_load[o];
-          rank += (v < my || (v == my && o < tid)) ? 1 : 0;
+          rank += (v < my || (v == my && o < bin)) ? 1 : 0;
         }
-        s_binof[rank] = tid;
+        rank += __shfl_xor(rank, 1);
+        rank += __shfl_xor(rank, 2);
+        rank += __shfl_xor(rank, 4);
+        if (part == 0) s_binof[rank] = bin;
       }
       __syncthreads();
       if (tid < kBins) {
         const int bin = s_binof[tid];
-        const int p = base + tid;
-        const int tile = p < nx ? sorted[a + p] : -1;
+        const int tile = s_rt[row * kBins + tid];
         const int wgl = bin >> 2, simd = bin & 3;
         const int wave = simd + 4 * (row % kWpS), t = row / kWpS;
         const int wg = wgl * 8 + x;                     // blockIdx & 7 == x: the workgroups one XCD gets
         int32_t* o = ent + ((((int64_t)rd * kRG + wg) * kCW + wave) * kTM + t) * 2;
-        const int m = tile >= 0 ? mask[tile] : 0;
+        const int m = s_rm[row * kBins + tid];
         o[0] = tile;
         o[1] = m;
         if (tile >= 0) s_load[bin] += __popc((unsigned)m) + 1;
@@ -771,8 +753,7 @@ extern "C" int spx_conv_ring_plan(const int32_t* pair, int64_t pair_ld, int kvol
   const int64_t tcap = ring_tcap(n_dst);
   hipLaunchKernelGGL(k_ring_mask, dim3((unsigned)((tcap + 15) / 16)), dim3(256), 0, s, pair, pair_ld, kvol, n_dst, d_n_dst, tcap,
                      plan);
-  hipLaunchKernelGGL(k_ring_scan, dim3(1), dim3(1024), 0, s, n_dst, d_n_dst, tcap, plan);
-  hipLaunchKernelGGL(k_ring_assign, dim3(8), dim3(1024), 0, s, tcap, kvol, plan);
+  hipLaunchKernelGGL(k_ring_assign, dim3(8), dim3(1024), 0, s, n_dst, d_n_dst, tcap, kvol, plan);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }

@@ -82,7 +82,7 @@ SIGNATURES = {
     "spx_wino_weight": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "spx_conv2d_wino": (_int, [_vp, _i64, _vp, _int, _int, _int, _int, _int, _vp, _vp, _int, _vp, _i64, _vp, _vp]),
     "spx_wino_stat_rows": (_i64, [_int, _int, _int]),
-    "spx_bn_relu_fwd_from_sums": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
+    "spx_bn_relu_fwd_from_sums": (_int, [_vp, _i64, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                                          _int, _vp, _i64, _vp, _vp, _vp]),
     "spx_wino_wgrad_ws_bytes": (_sz, [_int, _int]),
     "spx_conv2d_wino_wgrad": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _int, _int, _vp, _i64, _i64, _i64, _i64, _vp, _sz,

@@ -243,6 +243,9 @@ def _conv_backward(feats, weight, tables, rb, d_n_src, has_bias, dout, needs, d_
     return dfe, dw, db
 
 
+_EPILOGUE_STATS = os.environ.get("SPX_CONV_EPILOGUE_STATS", "1") != "0"     # dev knob
+
+
 class _SparseConvBNReLUFn(torch.autograd.Function):
     """Sparse conv + training-mode BatchNorm1d + ReLU of one `post_act_block` (reference spconv_backbone.py:9-35) as ONE
     autograd node: the same kernels as _SparseConvFn followed by _BNReLUFn, half the python / autograd bookkeeping per
@@ -255,9 +258,15 @@ class _SparseConvBNReLUFn(torch.autograd.Function):
         pair_f, ld_f, n_dst = tables[:3]
         cout, cin = weight.shape[0], weight.shape[-1]
         kvol = weight.numel() // (cout * cin)
-        out = _conv(feats, _packed(weight, 0), cout, kvol, pair_f, ld_f, n_dst, False, None, bias, False, d_n, rb)
-        y, mean, invstd = ops.bn_relu_fwd(out, gamma, beta, running_mean, running_var, momentum, eps, relu,
-                                          num_batches_tracked=nbt, d_n=d_n)
+        out, sums = _conv(feats, _packed(weight, 0), cout, kvol, pair_f, ld_f, n_dst, False, None, bias, False, d_n, rb,
+                          want_stats=True)
+        if sums is not None and _EPILOGUE_STATS:
+            # the batch sums came out of the convolution's epilogue (ring schedule): no statistics pass over `out`
+            y, mean, invstd = ops.bn_relu_fwd_from_sums(out, sums, gamma, beta, running_mean, running_var, momentum, eps, relu,
+                                                        num_batches_tracked=nbt, d_n=d_n)
+        else:
+            y, mean, invstd = ops.bn_relu_fwd(out, gamma, beta, running_mean, running_var, momentum, eps, relu,
+                                              num_batches_tracked=nbt, d_n=d_n)
         ctx.save_for_backward(feats, weight, out, gamma, beta, mean, invstd)
         ctx.tables, ctx.rb, ctx.d_n_src, ctx.has_bias, ctx.relu = tables, rb, d_n_src, bias is not None, relu
         ctx.d_n = d_n

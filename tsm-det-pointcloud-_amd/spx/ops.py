@@ -453,6 +453,9 @@ def conv_gemm_balanced(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k
 
 
 _RING = os.environ.get("SPX_CONV_RING", "1") != "0"              # dev knob: round-3 schedule (csrc/conv_ring.hip)
+# 32x32 / 32x64 / 64x32 are built too and 15-25 % faster than the one-tile-per-wave kernels launch by launch (kbench --ring),
+# but the training step gets SLOWER with them (299.9 vs 303.7 frames/s, same call): four more plans on the index stream and
+# 1024-thread persistent workgroups that have to wait for whole CUs beside the side-stream weight-gradient kernels
 _RING_SHAPES = {(64, 64)}
 if os.environ.get("SPX_CONV_RING_SHAPES"):                       # dev knob: "32x32,32x64,64x32,64x64"
     _RING_SHAPES = {tuple(int(v) for v in t.split("x")) for t in os.environ["SPX_CONV_RING_SHAPES"].split(",")}
@@ -711,9 +714,11 @@ def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, 
     return y, mean, invstd
 
 
-def bn_relu_fwd_from_sums(x, partial, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None):
+def bn_relu_fwd_from_sums(x, partial, gamma, beta, running_mean, running_var, momentum, eps, relu, num_batches_tracked=None,
+                          d_n=None):
     """bn_relu_fwd for rows x [N, C] whose per-block sums [rows, 2, C] the producing kernel already took (conv2d_wino with
-    stats=True): no statistics pass over x.  Returns y, save_mean, save_invstd."""
+    stats=True, conv_gemm_ring with want_stats=True): no statistics pass over x.  d_n: device-side live row count of a
+    static-capacity x.  Returns y, save_mean, save_invstd."""
     _need_gpu(x, partial, gamma, beta)
     lib = _lib.load()
     x = x.contiguous()
@@ -722,7 +727,7 @@ def bn_relu_fwd_from_sums(x, partial, gamma, beta, running_mean, running_var, mo
     y = torch.empty_like(x)
     mean = torch.empty((c,), dtype=torch.float32, device=x.device)
     invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
-    check(lib.spx_bn_relu_fwd_from_sums(_ptr(x), n, c, _ptr(partial), int(partial.shape[0]), _ptr(gamma), _ptr(beta),
+    check(lib.spx_bn_relu_fwd_from_sums(_ptr(x), n, _ptr(d_n), c, _ptr(partial), int(partial.shape[0]), _ptr(gamma), _ptr(beta),
                                         _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), float(momentum),
                                         float(eps), int(bool(relu)), _ptr(y), c, _ptr(mean), _ptr(invstd), _stream(x)),
           "spx_bn_relu_fwd_from_sums")
