@@ -246,8 +246,13 @@ int spx_conv_gemm_balanced(const float *src, int c_src, const float *w_packed, i
  * pass of the training-mode BatchNorm1d that follows (reference spconv_backbone.py:26-27,81), consumed by
  * spx_bn_relu_fwd_from_sums.  Every output row is the same sum over k in ascending order whatever the plan: bitwise
  * reproducible.  Channel pairs: (32|64) x (32|64); others SPX_ERR_UNSUPPORTED.  kvol <= 31. */
+/* spx_conv_ring_tiles_per_wave(set): tuning knob of spx_conv_ring_plan, process-wide.  0 (default): by size — a wave holds one
+ * 16-row tile per turn of the weight ring while one turn covers all live rows, two tiles (sharing the ring protocol of every
+ * offset) beyond that; 1 / 2: always that many (environment SPX_RING_TM presets it; tests and A/B runs).  Returns the
+ * setting; any other `set` only queries.  The plan records what it was dealt for and spx_conv_gemm_ring follows the plan. */
 size_t spx_conv_ring_plan_bytes(int64_t n_dst);
 int spx_conv_ring_stat_rows(void);
+int spx_conv_ring_tiles_per_wave(int set);
 int spx_conv_ring_plan(const int32_t *pair, int64_t pair_ld, int kvol, int64_t n_dst, const int64_t *d_n_dst, int32_t *plan,
                        spx_stream_t stream);
 int spx_conv_gemm_ring(const float *src, int64_t n_src, int c_src, const float *w_packed, int c_dst, int kvol, int flip_k,

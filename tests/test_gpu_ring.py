@@ -18,6 +18,17 @@ def _dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["by_size", "one_tile_per_wave", "two_tiles_per_wave"])
+def tiles_per_wave(request):
+    """Both decompositions of the kernel (ring_body1 / ring_body2), forced, and the plan's own choice by size."""
+    from spx import _lib
+    lib = _lib.load()
+    default = lib.spx_conv_ring_tiles_per_wave(-1)
+    assert lib.spx_conv_ring_tiles_per_wave(request.param) == request.param
+    yield request.param
+    lib.spx_conv_ring_tiles_per_wave(default)
+
+
 def _frame_indices(orc, cfg_id, nframes):
     from pcdet_amd.datasets import synthetic as syn
     geom = syn.CONFIGS[cfg_id]["geom"]
@@ -32,7 +43,7 @@ def _frame_indices(orc, cfg_id, nframes):
 
 def _plan_header(plan):
     h = plan[:32].cpu().numpy()
-    return dict(tiles=int(h[0]), units=int(h[1]), timeouts=int(h[2]), chunks=int(h[3]), rounds=h[8:16].tolist(),
+    return dict(tiles=int(h[0]), units=int(h[1]), timeouts=int(h[2]), chunks=int(h[3]), tm=int(h[4]), rounds=h[8:16].tolist(),
                 nchunks=h[16:24].tolist())
 
 
@@ -55,8 +66,11 @@ def _check_plan(ops, plan, pair, ld, K, n, live):
     kHdr = 32 + 8 * 96
     off_sorted = kHdr + (tcap + 3) // 4 * 4
     off_ent = off_sorted + (tcap + 3) // 4 * 4
-    R = max(hdr["rounds"])
-    ent = plan[off_ent: off_ent + R * 256 * 12 * 2].view(R, 256, 12, 2).cpu()
+    R, tm = max(hdr["rounds"]), hdr["tm"]
+    want = lib.spx_conv_ring_tiles_per_wave(-1)
+    assert tm == (want if want else (2 if (T + 7) // 8 > 384 else 1)) or (want == 0 and tm in (1, 2) and abs((T + 7) // 8 - 384) < 100)
+    assert R <= 1 or tm == 2 or want == 1
+    ent = plan[off_ent: off_ent + R * 256 * 12 * tm * 2].view(R, 256, 12 * tm, 2).cpu()
     seen = torch.zeros(T, dtype=torch.int64)
     for x in range(8):
         e = ent[:hdr["rounds"][x], x::8]                   # workgroups with blockIdx & 7 == x
@@ -187,7 +201,7 @@ def test_ring_empty_tiles_device_count_and_many_rounds(orc):
     x5 = torch.randn(n5, 64, generator=g).to(dev)
     plan5 = ops.conv_ring_plan(sub5.pair, sub5.ld, 27, n5)
     hdr = _check_plan(ops, plan5, sub5.pair, sub5.ld, 27, n5, n5)
-    assert max(hdr["rounds"]) >= 3
+    assert max(hdr["rounds"]) >= (3 if hdr["tm"] == 1 else 2)
     for flip in (False, True):
         assert torch.equal(ops.conv_gemm_ring(x5, wp, 64, 27, sub5.pair, sub5.ld, n5, plan5, flip_k=flip),
                            ops.conv_gemm(x5, wp, 64, 27, sub5.pair, sub5.ld, n5, flip_k=flip))

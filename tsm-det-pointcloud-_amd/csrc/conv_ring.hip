@@ -51,16 +51,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRG = 256;                  // workgroups: one per CU (LDS footprint admits one)
 constexpr int kCW = 12;                   // consumer waves per workgroup: waves w, w + 4 and w + 8 share a SIMD
-constexpr int kTM = 1;                    // 16-row tiles a wave holds per round (one turn of the ring each)
+constexpr int kTMmax = 2;                 // 16-row tiles a wave holds per round (one turn of the ring): 1 (k_conv_ring) or 2 (k_conv_ring2)
 constexpr int kSlots = 8;                 // weight ring depth
 constexpr int kLW = 4;                    // loader waves: loader w fills the offsets g = w (mod kLW)
 constexpr int kBins = 128;                // SIMD bins per XCD range: 32 workgroups x 4 SIMDs
 constexpr int kWpS = kCW / 4;              // consumer waves per SIMD
-constexpr int kDealRows = kWpS * kTM;     // deal rows per round: (tile slot, wave of the SIMD's group)
-constexpr int kPerRound = kBins * kDealRows;   // tiles one range places per round
+constexpr int kPerRound = kBins * kWpS;   // tiles one range places per round and tile slot (x tm)
 constexpr int kMaxCh = 96;                // chunks one XCD can be given (kMaxRows / 4096 / 8, rounded up)
 constexpr int kHdr = 32 + 8 * kMaxCh;     // plan header ints
-// header: [0] tiles T, [1] units U, [2] spin timeouts (debug), [3] chunks, [8..15] rounds of XCD x, [16..23] chunks of XCD x,
+// header: [0] tiles T, [1] units U, [2] spin timeouts (debug), [3] chunks, [4] tm, [8..15] rounds of XCD x, [16..23] chunks of XCD x,
 // [24..31] first position of XCD x in `sorted`, [32 + x * kMaxCh + j] = j-th chunk of XCD x
 // chunks = contiguous pieces of <= 4096 rows (the windows spx_conv_group sorts in): at least eight, a multiple of eight
 __host__ __device__ inline int ring_chunks(int64_t nlive) {
@@ -71,16 +70,19 @@ __host__ __device__ inline int ring_chunks(int64_t nlive) {
 __host__ __device__ inline int chunk_begin(int c, int T, int W) { return (int)((int64_t)c * T / W); }
 constexpr int kSpinLimit = 1 << 18;        // ~30 ms of polling: a protocol bug ends as plan[2] != 0, never as a hang
 
-// plan layout (int32): hdr[kHdr] | mask[tcap] | sorted[tcap] | ent[rcap][kRG][kCW][kTM][2]
+// plan layout (int32): hdr[kHdr] | mask[tcap] | sorted[tcap] | ent[rcap][kRG][kCW][tm][2]
 __host__ __device__ inline int64_t ring_tcap(int64_t n) { return (n + 15) / 16 + 1; }
 // rounds an XCD can need: it holds NC / 8 chunks of at most ceil(T / NC) tiles each
-__host__ __device__ inline int64_t ring_rcap(int64_t tcap) { return ((tcap + 7) / 8 + kMaxCh + kPerRound - 1) / kPerRound + 1; }
+__host__ __device__ inline int64_t ring_rcap(int64_t tcap, int tm) {
+  return ((tcap + 7) / 8 + kMaxCh + kPerRound * tm - 1) / (kPerRound * tm) + 1;
+}
 constexpr int64_t kMaxRows = (int64_t)60 * kPerRound * 8 * 16;   // rounds <= 64: a wave keeps its tiles on its 64 lanes (2.9 M rows)
 __host__ __device__ inline int64_t off_mask() { return kHdr; }
 __host__ __device__ inline int64_t off_sorted(int64_t tcap) { return off_mask() + (tcap + 3) / 4 * 4; }
 __host__ __device__ inline int64_t off_ent(int64_t tcap) { return off_sorted(tcap) + (tcap + 3) / 4 * 4; }
-__host__ __device__ inline int64_t plan_ints(int64_t tcap) {
-  return off_ent(tcap) + ring_rcap(tcap) * (int64_t)kRG * kCW * kTM * 2;
+__host__ __device__ inline int64_t plan_ints(int64_t tcap) {      // room for either tm
+  const int64_t e1 = ring_rcap(tcap, 1), e2 = ring_rcap(tcap, 2) * 2;
+  return off_ent(tcap) + (e1 > e2 ? e1 : e2) * (int64_t)kRG * kCW * 2;
 }
 
 // ---------------------------------------------------------------- plan 1: offset mask per 16-row tile
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void k_ring_mask(const int32_t* __restrict__ p
 // chunks per XCD (equal tile counts, each chunk a compact piece of the row order: the XCD's L2 holds those pieces), chosen
 // greedily by weight, heaviest chunk first to the XCD that carries the least.  Every block computes this (tiny, deterministic)
 // assignment for itself from the masks — no separate launch, no prefix array.
-__global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* d_n, int64_t tcap, int K,
+__global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* d_n, int64_t tcap, int K, int tm_want,
                                                       int32_t* __restrict__ plan) {
   __shared__ int s_hist[32];
   __shared__ int s_start[32];
@@ -129,6 +131,10 @@ __global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* 
   const int64_t nlive = spx_live_n(d_n, n);
   const int T = (int)((nlive + 15) / 16);
   const int NC = ring_chunks(nlive);
+  // tiles per wave and turn: every XCD gets NC / 8 chunks of at most ceil(T / NC) tiles.  One tile per wave keeps the row
+  // pipeline two units deep and is the faster kernel while ONE turn of the ring holds everything (measured at 2.4 tiles per
+  // SIMD: 64.6 vs 71.7 us); beyond that two tiles per wave halve the turns (5.0 tiles per SIMD: 106 vs 112 us)
+  const int tm = tm_want ? tm_want : ((NC / 8) * ((T + NC - 1) / NC) > kPerRound ? 2 : 1);
   const int32_t* mask = plan + off_mask();
   int32_t* sorted = plan + off_sorted(tcap);
   int32_t* ent = plan + off_ent(tcap);
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* 
     plan[1] = s_units;
     plan[2] = 0;
     plan[3] = NC;
+    plan[4] = tm;
   }
   for (int c = tid; c < NC; c += 1024) {
     const int my = s_cw[c];
@@ -209,7 +216,8 @@ __global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* 
     while (j + 1 < nch && s_cpre[j + 1] <= i) ++j;
     return s_cbeg[j] + (i - s_cpre[j]);
   };
-  const int rounds = (nx + kPerRound - 1) / kPerRound;
+  const int dealRows = kWpS * tm, perRound = kBins * dealRows;
+  const int rounds = (nx + perRound - 1) / perRound;
   if (tid == 0) plan[8 + x] = rounds;
   for (int i = tid; i < nx; i += 1024) atomicAdd(&s_hist[__popc((unsigned)mask[tile_at(i)])], 1);   // integer counts: order-free
   __syncthreads();
@@ -248,19 +256,19 @@ __global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* 
   }
   __threadfence_block();
   __syncthreads();
-  // entries of this range's 32 workgroups.  A round places kDealRows rows of kBins tiles (heaviest tiles first): one tile per
+  // entries of this range's 32 workgroups.  A round places dealRows = 3 * tm rows of kBins tiles (heaviest tiles first): one tile per
   // SIMD bin and row, the row's heaviest tile to the bin that carries the least so far IN THIS ROUND (the ring makes the
   // twelve waves of a workgroup walk a round together, so it is the per-round load of a SIMD that has to be level; a plain
   // snake over the sorted order left the fullest SIMD 14-32 % above the mean, and the launch lasts as long as the fullest
   // SIMD).  Row `h` of a round goes to wave simd + 4 * h.
   __shared__ int s_load[kBins];
   __shared__ int s_binof[kBins];
-  __shared__ int s_rt[kDealRows * kBins];  // the round's tiles (sorted order) and their masks: two dependent global reads
-  __shared__ int s_rm[kDealRows * kBins];  // once per round instead of once per row
+  __shared__ int s_rt[kWpS * kTMmax * kBins];   // the round's tiles (sorted order) and their masks: two dependent global
+  __shared__ int s_rm[kWpS * kTMmax * kBins];   // reads once per round instead of once per row
   for (int rd = 0; rd < rounds; ++rd) {
     if (tid < kBins) s_load[tid] = 0;
-    if (tid < kPerRound) {
-      const int p = rd * kPerRound + tid;
+    if (tid < perRound) {
+      const int p = rd * perRound + tid;
       const int tile = p < nx ? sorted[a + p] : -1;
       s_rt[tid] = tile;
       s_rm[tid] = tile >= 0 ? mask[tile] : 0;
@@ -269,9 +277,9 @@ __global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* 
     // rows of this round; a last row that does not fill every bin is placed FIRST (its tiles are the round's lightest): the
     // bins that end up with one tile more than the others must get lighter tiles from the full rows, and a greedy deal can
     // only arrange that if it sees the extra tiles before it places the heavy ones
-    const int left = nx - rd * kPerRound;
-    const int nrows = left >= kPerRound ? kDealRows : (left + kBins - 1) / kBins;
-    const bool partial = left < kPerRound && (left % kBins) != 0;
+    const int left = nx - rd * perRound;
+    const int nrows = left >= perRound ? dealRows : (left + kBins - 1) / kBins;
+    const bool partial = left < perRound && (left % kBins) != 0;
     for (int step = 0; step < nrows; ++step) {
       const int row = partial ? (step == 0 ? nrows - 1 : step - 1) : step;
       {
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* 
         const int wgl = bin >> 2, simd = bin & 3;
         const int wave = simd + 4 * (row % kWpS), t = row / kWpS;
         const int wg = wgl * 8 + x;                     // blockIdx & 7 == x: the workgroups one XCD gets
-        int32_t* o = ent + ((((int64_t)rd * kRG + wg) * kCW + wave) * kTM + t) * 2;
+        int32_t* o = ent + ((((int64_t)rd * kRG + wg) * kCW + wave) * tm + t) * 2;
         const int m = s_rm[row * kBins + tid];
         o[0] = tile;
         o[1] = m;
@@ -303,11 +311,11 @@ __global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* 
       __syncthreads();
     }
     // rows of the round that hold no tile at all: empty entries
-    for (int row = nrows; row < kDealRows; ++row) {
+    for (int row = nrows; row < dealRows; ++row) {
       if (tid < kBins) {
         const int wgl = tid >> 2, simd = tid & 3;
         const int wave = simd + 4 * (row % kWpS), t = row / kWpS;
-        int32_t* o = ent + ((((int64_t)rd * kRG + (wgl * 8 + x)) * kCW + wave) * kTM + t) * 2;
+        int32_t* o = ent + ((((int64_t)rd * kRG + (wgl * 8 + x)) * kCW + wave) * tm + t) * 2;
         o[0] = -1;
         o[1] = 0;
       }
@@ -316,19 +324,104 @@ __global__ __launch_bounds__(1024) void k_ring_assign(int64_t n, const int64_t* 
   }
 }
 
+
+// ---------------------------------------------------------------- the weight ring (shared by both kernels)
+// ready[slot] = g + 1 once the slot holds the weights of ring index g; done[slot] = consumer signals the slot has received in
+// all its visits; abort = set by the first spin that gave up (every later wait returns at once).
+struct RingCtl {
+  f32x4* ring;
+  int* ready;
+  int* done;
+  int* abort;
+  int32_t* plan;
+};
+
+__device__ __forceinline__ void ring_give_up(const RingCtl& c, int lane) {
+  if (lane == 0) {
+    atomicAdd(&c.plan[2], 1);
+    __hip_atomic_store(c.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
+// Loader waves: W_k of ring index g -> slot g % kSlots.  One fill is serial (wait for the slot, NF x 1 KiB LDS-DMA, wait for
+// them to land ~1.1 us, publish), so a single loader delivers a slice per ~1.3 us — slower than a round of light tiles consumes
+// them (first version: the launch was loader-bound).  kLW loaders take the indices round-robin: four fills in flight at a time.
+template <int NF>
+__device__ __forceinline__ void ring_fill(const RingCtl& c, const float* wp, int first, int total, int K, int lane) {
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+  for (int g = first; g < total; g += kLW) {
+    const int slot = g & (kSlots - 1);
+    const int k = g % K;
+    if (g >= kSlots) {                        // every consumer is through with the slot's previous index
+      const int target = kCW * (g / kSlots);
+      int spins = 0;
+      while (__hip_atomic_load(&c.done[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != target) {
+        if (spins < 8) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(6);
+        if (++spins > kSpinLimit || __hip_atomic_load(c.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          ring_give_up(c, lane);
+          break;
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp4 + ((size_t)k * NF + f) * 64 + lane),
+                                       (__attribute__((address_space(3))) void*)(&c.ring[(slot * NF + f) * 64]), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&c.ready[slot], g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
+// Consumer side.  A consumer signals a ring index only after it has SEEN the slot hold it (also indices it has no unit at):
+// then no signal of a slot's next visit can arrive before all signals of the current one (the loaders publish g only after
+// every consumer signalled g - kSlots), and the per-slot counters never mix visits.
+// One poll reads all kSlots words at once: ghz = first ring index NOT known to be published; indices below it need no
+// further LDS round trip (a slot cannot change before this wave has signalled it).  The wave that lags — the one every
+// other wave is waiting for — therefore runs its units without a single poll on its path (first version: two LDS round
+// trips of ~700 cycles per unit, on the critical wave).
+__device__ __forceinline__ void ring_wait(const RingCtl& c, int g, int& ghz, int lane) {
+#ifdef SPX_RING_NO_PROTO                       // ablation (dev builds): nobody waits, nobody signals; wrong results
+  return;
+#endif
+  if (g < ghz) return;
+  int spins = 0;
+  for (;;) {
+    const int j = lane & (kSlots - 1);
+    const int v = __hip_atomic_load(&c.ready[(g + j) & (kSlots - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned m = (unsigned)__ballot(v == g + j + 1) & ((1u << kSlots) - 1u);
+    ghz = g + __builtin_ctz(~m | (1u << kSlots));
+    if (g < ghz) break;
+    if (spins < 8) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
+    if (++spins > kSpinLimit || __hip_atomic_load(c.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+      ring_give_up(c, lane);
+      ghz = g + 1;
+      break;
+    }
+  }
+}
+__device__ __forceinline__ void ring_signal(const RingCtl& c, int g, int lane) {
+#ifndef SPX_RING_NO_PROTO
+  if (lane == 0) __hip_atomic_fetch_add(&c.done[g & (kSlots - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+
 // ---------------------------------------------------------------- the convolution
+// LDS of a workgroup, one object: ring | statistics scratch | control words (ready[kSlots], done[kSlots], abort, padding)
 template <int CS, int CD>
-__global__ __launch_bounds__(64 * (kCW + kLW)) void k_conv_ring(
+constexpr int ring_smem_f4() { return kSlots * (CD / 16) * (CS / 16) * 64 + kCW * 2 * CD / 4 + 2 * kSlots / 4 + 4; }
+
+// ---- one tile per wave and turn of the ring (plans with tm = 1)
+template <int CS, int CD>
+__device__ __forceinline__ void ring_body1(
     const float* __restrict__ src, int64_t n_src, const float* __restrict__ wp, const int32_t* __restrict__ pair, int64_t ld,
     int K, int flip, int64_t n, const int64_t* d_n, const float* __restrict__ scale, const float* __restrict__ shift,
     int relu, int32_t* __restrict__ plan, int64_t tcap, const int32_t* __restrict__ perm, float* __restrict__ dst,
-    float* __restrict__ stats) {
+    float* __restrict__ stats, f32x4* smem) {
   constexpr int NT = CD / 16;
   constexpr int JG = CS / 16;
   constexpr int NF = NT * JG;                 // 1 KiB weight fragments per offset
   constexpr int kStatF4 = kCW * 2 * CD / 4;   // cross-wave statistics scratch, in f32x4
-  // ONE LDS object: ring | statistics scratch | control words (ready[kSlots], done[kSlots])
-  __shared__ f32x4 smem[kSlots * NF * 64 + kStatF4 + 2 * kSlots / 4 + 4];   // (+4: abort word and padding)
   f32x4* ring = smem;
   float* s_stat = reinterpret_cast<float*>(smem + kSlots * NF * 64);
   int* s_ready = reinterpret_cast<int*>(smem + kSlots * NF * 64 + kStatF4);
@@ -341,42 +434,15 @@ __global__ __launch_bounds__(64 * (kCW + kLW)) void k_conv_ring(
   if (threadIdx.x < 2 * kSlots + 1) s_ready[threadIdx.x] = 0;
   __syncthreads();                            // the only workgroup barrier before the statistics epilogue
 
-  // ------------------------------------------------------------ loader waves: W_k of offset g -> slot g % kSlots
-  // One fill is serial (wait for the slot, 16 x 1 KiB LDS-DMA, wait for them to land ~1.1 us, publish), so a single loader
-  // delivers a slice per ~1.3 us — slower than a round of light tiles consumes them (first version: the launch was
-  // loader-bound).  kLW loaders take the offsets round-robin: four fills are in flight at a time.
+  const RingCtl ctl{ring, s_ready, s_done, s_abort, plan};
+  // ------------------------------------------------------------ loader waves
   if (wave >= kCW) {
-    const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
 #ifdef SPX_RING_NO_PROTO
     const int total = kSlots < R * K ? kSlots : R * K;
 #else
     const int total = R * K;
 #endif
-    for (int g = wave - kCW; g < total; g += kLW) {
-      const int slot = g & (kSlots - 1);
-      const int k = g % K;
-      if (g >= kSlots) {                      // every consumer is through with the slot's previous offset
-        const int target = kCW * (g / kSlots);
-        int spins = 0;
-        while (__hip_atomic_load(&s_done[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != target) {
-          if (spins < 8) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(6);
-          if (++spins > kSpinLimit || __hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-            if (lane == 0) {
-              atomicAdd(&plan[2], 1);
-              __hip_atomic_store(s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            break;
-          }
-        }
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int f = 0; f < NF; ++f)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp4 + ((size_t)k * NF + f) * 64 + lane),
-                                         (__attribute__((address_space(3))) void*)(&ring[(slot * NF + f) * 64]), 16, 0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(&s_ready[slot], g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    ring_fill<NF>(ctl, wp, wave - kCW, total, K, lane);
     if (stats) __syncthreads();               // matches the consumers' barrier of the statistics epilogue
     return;
   }
@@ -452,45 +518,13 @@ __global__ __launch_bounds__(64 * (kCW + kLW)) void k_conv_ring(
       a[jg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, voff + 64 * jg, 0, 0));
 #endif
   };
-  // ring protocol.  A consumer signals a ring index only after it has SEEN the slot hold it (also indices it has no unit at):
-  // then no signal of a slot's next visit can arrive before all signals of the current one (the loaders publish g only after
-  // every consumer signalled g - kSlots), and the per-slot counters never mix visits.
-  // One poll reads all kSlots words at once: ghz = first ring index NOT known to be published; indices below it need no
-  // further LDS round trip (a slot cannot change before this wave has signalled it).  The wave that lags — the one every
-  // other wave is waiting for — therefore runs its units without a single poll on its path (first version: two LDS round
-  // trips of ~700 cycles per unit, on the critical wave).
   int ghz = 0;
-  auto wait_ready = [&](int g) {
-#ifdef SPX_RING_NO_PROTO                       // ablation (dev builds): nobody waits, nobody signals; wrong results
-    return;
-#endif
-    if (g < ghz) return;
-    int spins = 0;
-    for (;;) {
-      const int j = lane & (kSlots - 1);
-      const int v = __hip_atomic_load(&s_ready[(g + j) & (kSlots - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const unsigned m = (unsigned)__ballot(v == g + j + 1) & ((1u << kSlots) - 1u);
-      ghz = g + __builtin_ctz(~m | (1u << kSlots));
-      if (g < ghz) break;
-      if (spins < 8) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
-      if (++spins > kSpinLimit || __hip_atomic_load(s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-        if (lane == 0) {
-          atomicAdd(&plan[2], 1);
-          __hip_atomic_store(s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        ghz = g + 1;
-        break;
-      }
-    }
-  };
+  auto wait_ready = [&](int g) { ring_wait(ctl, g, ghz, lane); };
   auto pass_indices = [&](int from, int to) {   // ring indices [from, to): seen, then signalled, in order
     for (int g = from; g < to; ++g) {
       wait_ready(g);
       asm volatile("" ::: "memory");
-#ifndef SPX_RING_NO_PROTO
-      if (lane == 0)
-        __hip_atomic_fetch_add(&s_done[g & (kSlots - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
+      ring_signal(ctl, g, lane);
     }
   };
 
@@ -729,12 +763,291 @@ ring_done:
   }
 }
 
+
+// ---------------------------------------------------------------- the convolution, two tiles per wave (plans with tm = 2)
+// Same ring, same loaders, same plan; a consumer wave holds TWO tiles per round (accumulators of both in registers) and walks
+// the ring indices in a STATIC loop: at index g = round * K + k it multiplies the rows of both tiles with W_k — the two
+// units share every weight fragment read from LDS (half the LDS reads per MFMA of k_conv_ring) and one wait / one signal of
+// the ring protocol.  The layers of the reference's blocks (40-90 k rows = 2.4-5.5 tiles per SIMD) then need ONE turn of the
+// ring instead of two; k_conv_ring paid ~15 us per turn in ring fill, drain and protocol.
+// No unit iterator: every load is unconditional (a tile that lacks offset k has entries of -1 there, which gather as
+// out-of-range zeros without memory traffic) and only the MFMA block is skipped, so the order and number of vector memory
+// operations per index is fixed and every s_waitcnt is a counted one.  One row buffer per tile: the 16 bytes of K-slice jg are
+// re-fetched for index g + 1 right after the MFMAs of g that read them were issued (a full index of head start), entries run
+// two indices ahead.
+template <int CS, int CD>
+__device__ __forceinline__ void ring_body2(
+    const float* __restrict__ src, int64_t n_src, const float* __restrict__ wp, const int32_t* __restrict__ pair, int64_t ld,
+    int K, int flip, int64_t n, const int64_t* d_n, const float* __restrict__ scale, const float* __restrict__ shift,
+    int relu, int32_t* __restrict__ plan, int64_t tcap, const int32_t* __restrict__ perm, float* __restrict__ dst,
+    float* __restrict__ stats, f32x4* smem) {
+  constexpr int NT = CD / 16;
+  constexpr int JG = CS / 16;
+  constexpr int NF = NT * JG;
+  constexpr int kStatF4 = kCW * 2 * CD / 4;
+  f32x4* ring = smem;
+  float* s_stat = reinterpret_cast<float*>(smem + kSlots * NF * 64);
+  int* s_ready = reinterpret_cast<int*>(smem + kSlots * NF * 64 + kStatF4);
+  int* s_done = s_ready + kSlots;
+  int* s_abort = s_done + kSlots;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int x = blockIdx.x & 7;
+  const int R = plan[8 + x];
+  if (threadIdx.x < 2 * kSlots + 1) s_ready[threadIdx.x] = 0;
+  __syncthreads();
+  const RingCtl ctl{ring, s_ready, s_done, s_abort, plan};
+  const int G = R * K;
+  if (wave >= kCW) {
+    ring_fill<NF>(ctl, wp, wave - kCW, G, K, lane);
+    if (stats) __syncthreads();
+    return;
+  }
+
+  const int nlive = (int)spx_live_n(d_n, n);
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CS * (int64_t)sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_pair =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(pair), 0, (int)((int64_t)K * ld * (int64_t)sizeof(int32_t)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dst =
+      __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(n * CD * (int64_t)sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_perm =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(perm), 0, perm ? (int)(n * (int64_t)sizeof(int32_t)) : 0, 0x00020000);
+  const int ldb = (int)(ld * 4), ld_i = (int)ld;
+
+  if (stats && q == 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      s_stat[(wave * 2 + 0) * CD + 16 * nt + r] = 0.f;
+      s_stat[(wave * 2 + 1) * CD + 16 * nt + r] = 0.f;
+    }
+  }
+
+  // this wave's tiles: slot t of round i on lane i (R <= 64, checked by the plan)
+  int tileAL = -1, tileBL = -1;
+  uint32_t maskAL = 0, maskBL = 0;
+  if (lane < R) {
+    const int4 e = *reinterpret_cast<const int4*>(plan + off_ent(tcap) + (((int64_t)lane * kRG + blockIdx.x) * kCW + wave) * 4);
+    tileAL = e.x, maskAL = (uint32_t)e.y, tileBL = e.z, maskBL = (uint32_t)e.w;      // mask bit = table row
+  }
+  auto tile_of = [&](int tl, int rd) -> int { return rd < R ? __builtin_amdgcn_readlane(tl, rd < R ? rd : 0) : -1; };
+  auto row_of = [&](int tile) -> int {         // the lane's table row of a tile, as a byte offset (an absent tile: row 0)
+    const int row = (tile > 0 ? tile : 0) * 16 + r;
+    return (row < ld_i ? row : ld_i - 1) * 4;
+  };
+  // rule entries of (tile, k): lane (r, q) reads the entry of row r (the four q copies coalesce).  -1 = no pair; an absent
+  // tile reads row 0 and is overridden with -1.  (Rows beyond the live count of the LAST tile read whatever the table holds
+  // there; their accumulator rows are never stored, and every gather is bounds-checked by the buffer hardware.)
+  auto load_id = [&](int rowb, int k, bool present) -> int32_t {
+    const int tr = flip ? K - 1 - k : k;
+    const int32_t v = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_pair, rowb, __builtin_amdgcn_readfirstlane(tr * ldb), 0);
+    return present ? v : -1;
+  };
+
+  f32x4 accA[NT], accB[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // epilogue of one tile (see k_conv_ring): C layout col = lane & 15, row = 4 * (lane >> 4) + e; rows beyond the live count
+  // get a store offset beyond the records, which the buffer hardware drops
+  auto write_tile = [&](f32x4 (&acc)[NT], int tile) {
+    if (tile >= 0) {
+      const int orow0 = tile * 16 + 4 * q;
+      int drow[4];
+      if (perm) {
+        const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(rs_perm, orow0 * 4, 0, 0);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) drow[e4] = (int)pv[e4];
+      } else {
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) drow[e4] = orow0 + e4;
+      }
+      float live[4];
+      int voff[4];
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const bool ok = orow0 + e4 < nlive;
+        live[e4] = ok ? 1.0f : 0.0f;
+        voff[e4] = ok ? drow[e4] * (CD * 4) + 4 * r : (int)0xFFFFFF00u;
+      }
+      const bool affine = scale != nullptr || shift != nullptr;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float sc = 1.0f, sh = 0.0f;
+        if (affine) {
+          sc = scale ? scale[16 * nt + r] : 1.0f;
+          sh = shift ? shift[16 * nt + r] : 0.0f;
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          float v = acc[nt][e4];
+          if (affine) v = v * sc + sh;
+          if (relu) v = v > 0.f ? v : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dst, voff[e4] + 64 * nt, 0, 0);
+          const float vl = v * live[e4];
+          s1 += vl;
+          s2 += vl * v;
+        }
+        if (stats) {
+          s1 += __shfl_xor(s1, 16);
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 16);
+          s2 += __shfl_xor(s2, 32);
+          if (q == 0) {
+            s_stat[(wave * 2 + 0) * CD + 16 * nt + r] += s1;
+            s_stat[(wave * 2 + 1) * CD + 16 * nt + r] += s2;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  constexpr int NP = NT / 2;
+  constexpr int kQ = 8;                         // fragment registers: reads run kAhead = kQ - 2 ahead of their group
+  constexpr int kAhead = kQ - 2 < NF ? kQ - 2 : NF;
+  static_assert(NT % 2 == 0, "pairs of accumulators");
+  f32x4 rA[JG], rB[JG], bq[kQ];
+
+  // ---- prologue: rows of index 0, entries of index 1
+  int tA = tile_of(tileAL, 0), tB = tile_of(tileBL, 0);
+  uint32_t mA = R > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)maskAL, 0) : 0u;
+  uint32_t mB = R > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)maskBL, 0) : 0u;
+  int rd1 = 0, k1 = 0;                          // (round, offset) of index g + 1, then g + 2 below
+  int t1A = tA, t1B = tB, rowA = row_of(tA), rowB = row_of(tB);
+  int32_t idA = load_id(rowA, 0, tA >= 0), idB = load_id(rowB, 0, tB >= 0);
+  {
+    const int vA = idA * (CS * 4) + 16 * q, vB = idB * (CS * 4) + 16 * q;
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg) {
+      rA[jg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, vA + 64 * jg, 0, 0));
+      rB[jg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, vB + 64 * jg, 0, 0));
+    }
+  }
+  auto advance = [&]() {                        // (rd1, k1) -> the next index; refreshes the tiles / rows it reads entries of
+    if (++k1 == K) {
+      k1 = 0;
+      ++rd1;
+      t1A = tile_of(tileAL, rd1);
+      t1B = tile_of(tileBL, rd1);
+      rowA = row_of(t1A);
+      rowB = row_of(t1B);
+    }
+  };
+  advance();                                    // index 1
+  idA = load_id(rowA, k1, t1A >= 0);
+  idB = load_id(rowB, k1, t1B >= 0);
+  advance();                                    // index 2
+
+  // the MFMAs of one tile at the current index: a stream of NF fragment reads through kQ registers, two reads (one group of
+  // eight MFMAs on two accumulators) ahead
+#define SPX_DUO_UNIT(ACC, ROWS)                                                                                        \
+  {                                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < kAhead; ++j) {                                                                \
+      const int gi = j >> 1, jg = gi / NP, nt = 2 * (gi % NP) + (j & 1);                                                \
+      bq[j % kQ] = Bf[(nt * JG + jg) * 64];                                                                             \
+    }                                                                                                                   \
+    _Pragma("unroll") for (int gi = 0; gi < JG * NP; ++gi) {                                                            \
+      const int jg = gi / NP, n0 = 2 * (gi % NP);                                                                       \
+      _Pragma("unroll") for (int j = 2 * gi + kAhead; j < 2 * gi + kAhead + 2; ++j) {                                   \
+        if (j < NF) {                                                                                                   \
+          const int gj = j >> 1, jj = gj / NP, nn = 2 * (gj % NP) + (j & 1);                                            \
+          bq[j % kQ] = Bf[(nn * JG + jj) * 64];                                                                         \
+        }                                                                                                               \
+      }                                                                                                                 \
+      _Pragma("unroll") for (int ee = 0; ee < 4; ++ee) {                                                                \
+        ACC[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ROWS[jg][ee], bq[(2 * gi) % kQ][ee], ACC[n0], 0, 0, 0);          \
+        ACC[n0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ROWS[jg][ee], bq[(2 * gi + 1) % kQ][ee], ACC[n0 + 1], 0, 0, 0); \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  }
+#define SPX_DUO_FETCH(ROWS, V)                                                                                         \
+  {                                                                                                                     \
+    _Pragma("unroll") for (int jg = 0; jg < JG; ++jg)                                                                   \
+      ROWS[jg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, V + 64 * jg, 0, 0));           \
+    asm volatile("" ::: "memory");                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  }
+
+  int ghz = 0, k = 0, rd = 0;
+  for (int g = 0; g < G; ++g) {
+    // entries of index g + 2 (older than this index's gathers: complete, without a wait of their own, when g + 1 needs them)
+    const int32_t idA2 = load_id(rowA, k1, t1A >= 0), idB2 = load_id(rowB, k1, t1B >= 0);
+    const int vA = idA * (CS * 4) + 16 * q, vB = idB * (CS * 4) + 16 * q;     // rows of index g + 1
+    const int tr = flip ? K - 1 - k : k;
+    const bool pA = tA >= 0 && ((mA >> tr) & 1u), pB = tB >= 0 && ((mB >> tr) & 1u);
+    ring_wait(ctl, g, ghz, lane);
+    asm volatile("" ::: "memory");
+    const f32x4* Bf = ring + (size_t)(g & (kSlots - 1)) * NF * 64 + lane;
+    // tile A, then its rows of index g + 1 (in flight across tile B's MFMAs); tile B likewise (in flight across tile A's of g + 1)
+    if (pA) SPX_DUO_UNIT(accA, rA)
+    SPX_DUO_FETCH(rA, vA)
+    if (pB) SPX_DUO_UNIT(accB, rB)
+    SPX_DUO_FETCH(rB, vB)
+    // this wave's reads of the slot are complete (the MFMAs that consume them were issued)
+    asm volatile("" ::: "memory");
+    ring_signal(ctl, g, lane);
+    idA = idA2;
+    idB = idB2;
+    advance();
+    if (++k == K) {                              // the round's last offset: write both tiles, next round's tiles
+      write_tile(accA, tA);
+      write_tile(accB, tB);
+      k = 0;
+      ++rd;
+      tA = tile_of(tileAL, rd);
+      tB = tile_of(tileBL, rd);
+      mA = rd < R ? (uint32_t)__builtin_amdgcn_readlane((int)maskAL, rd < R ? rd : 0) : 0u;
+      mB = rd < R ? (uint32_t)__builtin_amdgcn_readlane((int)maskBL, rd < R ? rd : 0) : 0u;
+    }
+  }
+#undef SPX_DUO_UNIT
+#undef SPX_DUO_FETCH
+
+  if (stats) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * CD; i += 64 * kCW) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < kCW; ++w) s += s_stat[w * 2 * CD + i];      // fixed order
+      stats[(size_t)blockIdx.x * 2 * CD + i] = s;
+    }
+  }
+}
+
+// One launch serves both decompositions: the plan says which one its entries were dealt for (plan[4], chosen by
+// k_ring_assign from the LIVE row count, which the host does not know under static capacities).
+template <int CS, int CD>
+__global__ __launch_bounds__(64 * (kCW + kLW)) void k_conv_ring(
+    const float* __restrict__ src, int64_t n_src, const float* __restrict__ wp, const int32_t* __restrict__ pair, int64_t ld,
+    int K, int flip, int64_t n, const int64_t* d_n, const float* __restrict__ scale, const float* __restrict__ shift,
+    int relu, int32_t* __restrict__ plan, int64_t tcap, const int32_t* __restrict__ perm, float* __restrict__ dst,
+    float* __restrict__ stats) {
+  __shared__ f32x4 smem[ring_smem_f4<CS, CD>()];
+  if (plan[4] == 2)
+    ring_body2<CS, CD>(src, n_src, wp, pair, ld, K, flip, n, d_n, scale, shift, relu, plan, tcap, perm, dst, stats, smem);
+  else
+    ring_body1<CS, CD>(src, n_src, wp, pair, ld, K, flip, n, d_n, scale, shift, relu, plan, tcap, perm, dst, stats, smem);
+}
+
 template <int CS, int CD>
 static void launch_ring(const float* src, int64_t n_src, const float* wp, const int32_t* pair, int64_t ld, int K, int flip,
                         int64_t n, const int64_t* d_n, const float* scale, const float* shift, int relu, int32_t* plan,
                         const int32_t* perm, float* dst, float* stats, hipStream_t s) {
   hipLaunchKernelGGL((k_conv_ring<CS, CD>), dim3(kRG), dim3(64 * (kCW + kLW)), 0, s, src, n_src, wp, pair, ld, K, flip, n, d_n,
                      scale, shift, relu, plan, ring_tcap(n), perm, dst, stats);
+}
+
+// tiles per wave and turn of the ring of the plans this library deals: 0 = by size (two as soon as one tile per wave would
+// need a second turn), 1 / 2 = always that (SPX_RING_TM in the environment, or spx_conv_ring_tiles_per_wave(); tests, A/B runs)
+int g_ring_tm = -1;
+int ring_tm() {
+  if (g_ring_tm < 0) {
+    const char* e = getenv("SPX_RING_TM");
+    g_ring_tm = e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0;
+  }
+  return g_ring_tm;
 }
 
 }  // namespace
@@ -745,6 +1058,11 @@ extern "C" size_t spx_conv_ring_plan_bytes(int64_t n_dst) {
 
 extern "C" int spx_conv_ring_stat_rows(void) { return kRG; }
 
+extern "C" int spx_conv_ring_tiles_per_wave(int set) {
+  if (set >= 0 && set <= 2) g_ring_tm = set;
+  return ring_tm();
+}
+
 extern "C" int spx_conv_ring_plan(const int32_t* pair, int64_t pair_ld, int kvol, int64_t n_dst, const int64_t* d_n_dst,
                                   int32_t* plan, spx_stream_t stream) {
   if (!pair || !plan || kvol <= 0 || kvol > 31 || n_dst <= 0 || pair_ld < n_dst) return SPX_ERR_INVALID_ARG;
@@ -753,7 +1071,7 @@ extern "C" int spx_conv_ring_plan(const int32_t* pair, int64_t pair_ld, int kvol
   const int64_t tcap = ring_tcap(n_dst);
   hipLaunchKernelGGL(k_ring_mask, dim3((unsigned)((tcap + 15) / 16)), dim3(256), 0, s, pair, pair_ld, kvol, n_dst, d_n_dst, tcap,
                      plan);
-  hipLaunchKernelGGL(k_ring_assign, dim3(8), dim3(1024), 0, s, n_dst, d_n_dst, tcap, kvol, plan);
+  hipLaunchKernelGGL(k_ring_assign, dim3(8), dim3(1024), 0, s, n_dst, d_n_dst, tcap, kvol, ring_tm(), plan);
   SPX_CHECK_LAUNCH();
   return SPX_OK;
 }

@@ -56,6 +56,7 @@ SIGNATURES = {
                                       _vp, _sz, _vp]),
     "spx_conv_ring_plan_bytes": (_sz, [_i64]),
     "spx_conv_ring_stat_rows": (_int, []),
+    "spx_conv_ring_tiles_per_wave": (_int, [_int]),
     "spx_conv_ring_plan": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp]),
     "spx_conv_gemm_ring": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp,
                                   _vp, _vp]),
