@@ -471,6 +471,48 @@ def test_graphed_static_capacity_forward_matches_dynamic():
     assert "spconv2" in bad and bad["spconv2"][0] > bad["spconv2"][1]
 
 
+def test_folded_batchnorm_cache_follows_parameter_writes():
+    """Inference folds BatchNorm into the conv epilogues once per module (spx.functional.folded_bn) instead of five
+    elementwise launches per layer and forward; the cache must follow every write to a parameter or running statistic —
+    in eager mode (version counters) and under a captured hipGraph (the fold is rebuilt in place before the replay)."""
+    from pcdet_amd.models.inference import GraphedDetector
+    from spx import functional as F_
+    _cfg, ds, model = _build(seed=12)
+    dev = torch.device("cuda:0")
+    model.to(dev).eval()
+    b = ds.collate_batch([ds[0], ds[1]])
+    pts = torch.from_numpy(b["points"]).to(dev)
+
+    def eager(cache):
+        if not cache:
+            F_._FOLDED.clear()
+        with torch.no_grad():
+            bd = {"points": pts, "batch_size": 2}
+            for m in model.module_list:
+                bd = m(bd)
+        return bd["spatial_features"].clone(), bd["batch_box_preds"].clone()
+
+    runner = GraphedDetector(model, batch_size=2, max_points=9000)
+    first = eager(True)
+    assert len(F_._FOLDED) >= 12                     # the sparse layers and the BEV blocks went through the cache
+    assert torch.equal(runner(pts)["spatial_features"], first[0])
+    bns = [m for m in model.modules() if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))]
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for m in bns:                                # what an optimizer step / load_state_dict does: in-place writes
+            m.weight.mul_((torch.rand(m.num_features, generator=g) + 0.5).to(dev))
+            m.running_mean.add_((0.1 * torch.randn(m.num_features, generator=g)).to(dev))
+            m.running_var.copy_((torch.rand(m.num_features, generator=g) + 0.5).to(dev))
+    cached = eager(True)
+    fresh = eager(False)
+    assert not torch.equal(cached[0], first[0])
+    assert torch.equal(cached[0], fresh[0])
+    assert float((cached[1] - fresh[1]).abs().max()) < 1e-5      # MIOpen's head convolutions: reproducible to ~1e-7 only
+    out = runner(pts)
+    assert torch.equal(out["spatial_features"], fresh[0])
+    assert float((out["batch_box_preds"] - fresh[1]).abs().max()) < 1e-5
+
+
 def test_bev_block_rewrites_match_plain_sequential():
     """BaseBEVBackbone._run_block (pad folded into the conv, fused BN2d+ReLU through libspx on the channels_last row
     view) against nn.Sequential.forward of the very same modules: outputs, input gradient, parameter gradients and

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from spx import ops
-from spx.functional import (bn_relu_cat_train, bn_relu_train, dense as densify_rows, sparse_conv, wino_conv2d,
+from spx.functional import (bn_relu_cat_train, bn_relu_train, dense as densify_rows, folded_bn, sparse_conv, wino_conv2d,
                             wino_conv2d_ok, wino_conv_bn_relu_train)
 
 # below this many activations the three-launch fused BN kernel is launch-bound and MIOpen's BN is faster (measured on
@@ -50,8 +50,8 @@ def _run_block(seq, x, start=0):
                 x = wino_conv_bn_relu_train(x, m, nxt)
                 i += 3
             elif nxt is not None and isinstance(nn2, nn.ReLU) and _eval_bn_ok(nxt, x, check_layout=False):
-                scale = nxt.weight * torch.rsqrt(nxt.running_var + nxt.eps)
-                x = wino_conv2d(x, m.weight, scale=scale, shift=nxt.bias - nxt.running_mean * scale, relu=True)
+                scale, shift, _ = folded_bn(nxt)
+                x = wino_conv2d(x, m.weight, scale=scale, shift=shift, relu=True)
                 i += 3
             else:
                 x = wino_conv2d(x, m.weight)
@@ -100,7 +100,7 @@ def _eval_bn_ok(m, x, check_layout=True):
 
 
 def _bn_eval_rows(rows, bn, relu, out=None):
-    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    _scale, _shift, invstd = folded_bn(bn)
     return ops.bn_apply(rows, bn.running_mean, invstd, bn.weight, bn.bias, relu, out=out)
 
 

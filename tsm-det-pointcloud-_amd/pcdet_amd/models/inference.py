@@ -14,6 +14,8 @@ it when convenient).
 """
 import torch
 
+from spx.functional import refresh_folded_bn
+
 DEFAULT_LEVEL_FACTORS = {'spconv2': 2.0, 'spconv3': 2.0, 'spconv4': 1.0, 'spconv_down2': 1.0}
 
 
@@ -90,6 +92,7 @@ class GraphedDetector(object):
         self.points[:n].copy_(points, non_blocking=True)
         if n < self.max_points:
             self.points[n:] = self._pad_row
+        refresh_folded_bn(self.model)        # BatchNorm folds the graph captured: rebuilt in place if a parameter was written
         self.graph.replay()
         return self.out
 

@@ -48,6 +48,48 @@ def _packed(weight, mode):
 
 
 _BANKS = weakref.WeakKeyDictionary()       # first conv module of a stack -> its PackedBank: released with the model
+_FOLDED = weakref.WeakKeyDictionary()      # eval-mode BatchNorm module -> (key, scale, shift, invstd): released with the model
+
+
+def folded_bn(bn, conv_bias=None):
+    """(scale, shift, invstd) of an inference-mode BatchNorm on its running statistics, folded for a conv epilogue:
+    y = conv * scale + shift, scale = gamma / sqrt(var + eps), shift = beta - mean * scale (+ conv_bias * scale).
+    Cached per module: the five elementwise launches of the fold (rsqrt, mul, mul, sub, add) ran once per layer and FORWARD
+    — 140 launches of ~4.7 us per cfg-5 forward, 0.6 ms of 4 (rocprofv3, round 3).  The cached tensors keep their storage: when
+    a parameter or statistic was written since (its version counter moved, or it was replaced) they are recomputed IN PLACE, so
+    a hipGraph that captured them picks the new values up (refresh_folded_bn)."""
+    ts = (bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.running_mean, bn.running_var, conv_bias)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts) + (float(bn.eps),)
+    hit = _FOLDED.get(bn)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2], hit[3]
+    with torch.no_grad():
+        inv = torch.rsqrt(bn.running_var + bn.eps)
+        scale = inv * bn.weight if bn.affine else inv.clone()
+        shift = -bn.running_mean * scale
+        if bn.affine:
+            shift = shift + bn.bias
+        if conv_bias is not None:
+            shift = shift + conv_bias * scale
+        if hit is not None and hit[1].shape == scale.shape and hit[1].device == scale.device:
+            hit[1].copy_(scale)
+            hit[2].copy_(shift)
+            hit[3].copy_(inv)
+            scale, shift, inv = hit[1], hit[2], hit[3]
+        else:
+            scale, shift, inv = scale.contiguous(), shift.contiguous(), inv.contiguous()
+    _FOLDED[bn] = (key, scale, shift, inv, weakref.ref(conv_bias) if conv_bias is not None else None)
+    return scale, shift, inv
+
+
+def refresh_folded_bn(model):
+    """Bring the cached folds of `model`'s BatchNorm modules up to date (in place) — call before replaying a hipGraph that was
+    captured in inference mode when parameters may have been written since (GraphedDetector does).  Host-side version checks
+    only while nothing changed."""
+    for m in model.modules():
+        hit = _FOLDED.get(m)
+        if hit is not None:
+            folded_bn(m, hit[4]() if hit[4] is not None else None)
 
 
 def pack_all(convs):

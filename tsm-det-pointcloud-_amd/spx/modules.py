@@ -11,6 +11,8 @@ from collections import OrderedDict
 
 import os
 
+import weakref
+
 import torch
 from torch import nn
 
@@ -170,16 +172,9 @@ def _fusable_tail(conv, mods, i):
     bn = mods[i + 1]
     if not isinstance(bn, nn.BatchNorm1d) or bn.training or bn.running_mean is None:
         return None
-    with torch.no_grad():
-        inv = torch.rsqrt(bn.running_var + bn.eps)
-        scale = inv * bn.weight if bn.affine else inv
-        shift = -bn.running_mean * scale
-        if bn.affine:
-            shift = shift + bn.bias
-        if conv.bias is not None:
-            shift = shift + conv.bias * scale
+    scale, shift, _ = F_.folded_bn(bn, conv.bias)
     relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
-    return scale.contiguous(), shift.contiguous(), relu, (3 if relu else 2)
+    return scale, shift, relu, (3 if relu else 2)
 
 
 def _triple(v, ndim=3):
