@@ -67,7 +67,12 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the forward / backbone / rulebook / Waymo extras")
     ap.add_argument("--graph", action="store_true",
                     help="single-GPU training: replay forward + backward as one hipGraph (GraphedTrainStep) instead of issuing "
-                         "them kernel by kernel; same rate on a fast host (the step is GPU-bound), insurance on a slow one")
+                         "them kernel by kernel; measured SLOWER than eager on MI355X (298 vs 310 frames/s, DESIGN.md 6b)")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="rehearse the N > 1 code path with one rank: RCCL process group of size 1 + the DDP wrapper")
+    ap.add_argument("--plain-ddp", action="store_true",
+                    help="N > 1: torch's DistributedDataParallel as the reference wraps it, without the late reduction of the "
+                         "convolution weights (A/B)")
     ap.add_argument("--dynamic", action="store_true",
                     help="training with exact-size sparse tensors (one host read per strided rule table) instead of the "
                          "host-sync-free static-capacity path")
@@ -721,7 +726,12 @@ def main():
         miopen_db = use_tuned_db()          # before the first convolution of the process
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_ddp:
+        if world == 1:                       # --force-ddp: the N > 1 code path (RCCL process group, DDP) with one rank
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
         world = dist.get_world_size()        # what RCCL actually joined
         if world != args.gpus:
@@ -734,11 +744,14 @@ def main():
     batch = args.batch or synthetic.CONFIGS[args.cfg]["batch"]
     cfg, ds, model, optimizer, sched = build(args.cfg, device, args.dense_dtype)
     model.train(args.mode == "train")
-    if world > 1 and args.mode == "train":
+    if (world > 1 or args.force_ddp) and args.mode == "train":
         # broadcast_buffers stays at DDP's default (True), as in the reference (tools/train.py:154-155): BatchNorm running
-        # statistics are rank 0's on every rank
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=8,
-                                                          gradient_as_bucket_view=True)
+        # statistics are rank 0's on every rank.  wrap_ddp = DistributedDataParallel with the convolution weights' gradients
+        # reduced after the end-of-pass join of the weight-gradient stream instead of bucket by bucket (plain DDP serialises
+        # that stream with the backward pass: -7 % per GPU, pcdet_amd/utils/ddp_utils.py)
+        from pcdet_amd.utils.ddp_utils import wrap_ddp
+        model = wrap_ddp(model, late_reduce=not args.plain_ddp, device_ids=[local_rank], bucket_cap_mb=8,
+                         gradient_as_bucket_view=True)
     batches = make_batches(ds, args.cfg, batch, rank, device)
     caps = None
     if args.mode == "train" and not args.dynamic:
@@ -868,7 +881,7 @@ def main():
         line["cpu_baseline"] = cpu_baseline(args.cfg, args.mode)
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -84,3 +84,73 @@ def test_ddp_gloo_world2_gradient_allreduce(tmp_path):
         worst = max(worst, float((r0["grads"][n] - want).abs().max() / want.abs().max().clamp_min(1e-12)))
     assert worst < 1e-4, worst
     assert float(r0["loss"]) != float(r1["loss"])   # different frames per rank (weak scaling)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# pcdet_amd.utils.ddp_utils.wrap_ddp: convolution weights outside DDP's buckets, reduced as one flat buffer at the end of the pass
+
+def _tiny_model():
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3, padding=1, bias=False), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                               torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 3))
+
+
+def _tiny_data(i):
+    g = torch.Generator().manual_seed(100 + i)
+    return torch.randn(2, 4, 6, 6, generator=g), torch.randn(2, 3, generator=g)
+
+
+def _late_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tsm-det-pointcloud-_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from pcdet_amd.utils.ddp_utils import late_reduced_parameters, wrap_ddp
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _tiny_model()
+    late = late_reduced_parameters(model)
+    assert sorted(late) == ["0.weight", "3.weight"]
+    if rank == 1:
+        with torch.no_grad():
+            model[0].weight.add_(1.0)                   # must be overwritten by rank 0's values
+    ddp = wrap_ddp(model)
+    assert all(getattr(p, "_spx_manual_reduce", False) for p in late.values())
+    out = {}
+    # one synchronised step; then two accumulated micro-steps under no_sync() + a synchronised one
+    x, y = _tiny_data(rank)
+    torch.nn.functional.mse_loss(ddp(x), y).backward()
+    out["step"] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    out["w0"] = model[0].weight.detach().clone()
+    ddp.zero_grad(set_to_none=True)
+    with ddp.no_sync():
+        x, y = _tiny_data(10 + rank)
+        torch.nn.functional.mse_loss(ddp(x), y).backward()
+    x, y = _tiny_data(20 + rank)
+    torch.nn.functional.mse_loss(ddp(x), y).backward()
+    out["accum"] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    torch.save(out, os.path.join(out_dir, "late%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_wrap_ddp_late_reduction_world2(tmp_path):
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_late_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "late0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(tmp_path, "late1.pt"), weights_only=True)
+    assert torch.equal(r0["w0"], r1["w0"]) and torch.equal(r0["w0"], _tiny_model()[0].weight.detach())
+    torch.set_num_threads(1)
+
+    def grads(ids):
+        m = _tiny_model()
+        for i in ids:
+            x, y = _tiny_data(i)
+            torch.nn.functional.mse_loss(m(x), y).backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+    for key, per_rank in (("step", ([0], [1])), ("accum", ([10, 20], [11, 21]))):
+        a, b = grads(per_rank[0]), grads(per_rank[1])
+        for n in a:
+            assert torch.equal(r0[key][n], r1[key][n]), (key, n)              # every rank holds the same gradients
+            want = 0.5 * (a[n] + b[n])                                        # ... the mean over ranks, late-reduced or not
+            assert float((r0[key][n] - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), (key, n)

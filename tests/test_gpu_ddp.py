@@ -49,7 +49,7 @@ def _batch(ds, fid, dev, static, model):
     return bd
 
 
-def _worker(rank, world, port, out_dir, static, freeze_bn=False):
+def _worker(rank, world, port, out_dir, static, freeze_bn=False, late=False):
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -58,20 +58,35 @@ def _worker(rank, world, port, out_dir, static, freeze_bn=False):
     dev = torch.device("cuda:0")
     ds, model = _model_and_data(freeze_bn)
     model.to(dev)
-    ddp = torch.nn.parallel.DistributedDataParallel(model, bucket_cap_mb=8, gradient_as_bucket_view=True)
+    if late:
+        # pcdet_amd.utils.ddp_utils.wrap_ddp: conv weights out of DDP's buckets, joined + all-reduced at the end of the pass
+        from pcdet_amd.utils.ddp_utils import late_reduced_parameters, wrap_ddp
+        from spx import functional as F_
+        if rank == 1:                          # wrap_ddp must bring rank 0's values to every rank, as DDP does for the rest
+            with torch.no_grad():
+                next(iter(late_reduced_parameters(model).values())).add_(1.0)
+        ddp = wrap_ddp(model, bucket_cap_mb=8, gradient_as_bucket_view=True)
+        joins = []
+        orig = F_._join_after_backward
+        F_._join_after_backward = lambda main, side, keep: (joins.append(1), orig(main, side, keep))[1]
+    else:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, bucket_cap_mb=8, gradient_as_bucket_view=True)
     ret, _tb, _ = ddp(_batch(ds, rank, dev, static, model))      # rank r trains on frame r (DistributedSampler-style)
     ret["loss"].backward()
     ops.check_status(dev)
+    if late:
+        assert len(joins) >= 10, len(joins)    # the weight gradients kept their end-of-pass join under the process group
     grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters()}
     torch.save({"loss": ret["loss"].detach().cpu(), "grads": grads}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("static,freeze_bn", [(False, False), (True, False), (True, True)])
-def test_ddp_two_ranks_on_the_hip_path(tmp_path, static, freeze_bn):
-    world, port = 2, 29600 + (os.getpid() % 2000) + (7 if static else 0) + (13 if freeze_bn else 0)
-    mp.spawn(_worker, args=(world, port, str(tmp_path), static, freeze_bn), nprocs=world, join=True)
+@pytest.mark.parametrize("static,freeze_bn,late", [(False, False, False), (True, False, False), (True, True, False),
+                                                   (True, False, True), (True, True, True)])
+def test_ddp_two_ranks_on_the_hip_path(tmp_path, static, freeze_bn, late):
+    world, port = 2, 29600 + (os.getpid() % 2000) + (7 if static else 0) + (13 if freeze_bn else 0) + (29 if late else 0)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), static, freeze_bn, late), nprocs=world, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=True)
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=True)
     for n in r0["grads"]:                       # after the all-reduce every rank holds the same (averaged) gradients

@@ -124,6 +124,7 @@ def pack_all(convs):
 
 
 _ASYNC_WGRAD = os.environ.get("SPX_ASYNC_WGRAD", "1") != "0"            # dev knob
+_DEFER_JOIN = os.environ.get("SPX_WGRAD_DEFER_JOIN", "1") != "0"       # dev knob: 0 = join after every launch (what DDP gets)
 _SIDE_STREAMS = {}
 
 
@@ -185,12 +186,15 @@ def _nobody_reads_before_the_optimizer(weight):
     at once: accumulation into an existing .grad, a non-leaf weight (the gradient travels on through view / permute nodes and
     is copied into the parameter's layout), tensor hooks, and DistributedDataParallel, whose per-parameter hook copies the
     gradient into its bucket as soon as it is accumulated (assumed whenever a process group is up)."""
-    if not weight.is_leaf or weight.grad is not None or torch.cuda.is_current_stream_capturing():
+    if not _DEFER_JOIN or not weight.is_leaf or weight.grad is not None or torch.cuda.is_current_stream_capturing():
         return False
     if getattr(weight, "_backward_hooks", None) or getattr(weight, "_post_accumulate_grad_hooks", None):
         return False
     dist = torch.distributed
-    return not (dist.is_available() and dist.is_initialized())
+    if dist.is_available() and dist.is_initialized():
+        # pcdet_amd.utils.ddp_utils.wrap_ddp takes this weight out of DDP's buckets and reduces it after the end-of-pass join
+        return bool(getattr(weight, "_spx_manual_reduce", False))
+    return True
 
 
 def _conv(src, wp, c_dst, kvol, pair, ld, n_dst, flip, scale, shift, relu, d_n, rb, want_stats=False):
