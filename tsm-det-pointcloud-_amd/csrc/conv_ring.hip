@@ -8,22 +8,25 @@
 // a read-back (26 MB of slab traffic per call, two drain + ticket periods per workgroup), and the barrier drains the row
 // prefetch once per unit.  Measured: MFMA pipe 55 % busy, 0.34 of the fp32 MFMA peak.
 //
-// Here one workgroup per CU (8 consumer waves, two per SIMD, + 1 loader wave) keeps the accumulators of ALL its tiles in
-// registers from the first offset to the last (up to 3 tiles per wave and round; more rows -> more rounds):
+// Here one workgroup per CU (12 consumer waves, three per SIMD, + 4 loader waves; <= 128 VGPRs) keeps the accumulators of its
+// tiles in registers from the first offset to the last (one or two tiles per wave and turn of the ring; more rows -> more turns):
 //   * no tile is ever shared: no slabs, no tickets, no combine, every output row is written once by the wave that summed
 //     it over k in ascending order (bitwise reproducible, and independent of the plan);
-//   * the K weight slices W_k stream through an 8-slot LDS ring (16 KiB each at 64 x 64) filled by the loader wave with
-//     LDS-DMA; consumers and loader meet through two LDS words per slot (ready = which offset the slot holds, done = how
-//     many consumers are through with it) — NO workgroup barrier in the main loop, waves drift up to 7 offsets apart, so a
+//   * the K weight slices W_k stream through an 8-slot LDS ring (16 KiB each at 64 x 64) filled by the loader waves with
+//     LDS-DMA; consumers and loaders meet through two LDS words per slot (ready = which ring index the slot holds, done = how
+//     many consumer signals it has received) — NO workgroup barrier in the main loop, waves drift up to 7 offsets apart, so a
 //     wave whose tiles lack an offset simply runs ahead instead of waiting for its neighbours;
-//   * each wave walks its own (tile, offset) units with a three-deep register pipeline: rule entries of unit i+3, rows of
-//     unit i+2 (raw buffer loads: an entry of -1 is an out-of-range offset and reads as zeros — no select, no clamp) and the
-//     MFMAs of unit i; buffers rotate by NAME (the loop is unrolled by three), so no in-flight register is ever copied and
-//     the compiler's counted vmcnt waits leave the newest gather in flight across the whole MFMA block;
-//   * spx_conv_ring_plan (cached per rule table like the balanced plan) cuts the tiles into eight contiguous ranges of equal
-//     unit count (one per XCD: the range's rows stay in that XCD's L2), orders the tiles of a range by their number of
-//     non-empty offsets and deals them in a snake over the range's 128 SIMD bins — two waves per bin — so every SIMD's MFMA
-//     pipe gets the same number of units (+- one light tile);
+//   * ring_body1 (one tile per wave and turn): each wave walks its own (tile, offset) units with a register pipeline across
+//     turns — rule entries of unit i+2, rows of unit i+1 (raw buffer loads: an entry of -1 is an out-of-range offset and reads
+//     as zeros — no select, no clamp) and the MFMAs of unit i; the two row buffers rotate by NAME (the loop is unrolled by two),
+//     so no in-flight register is ever copied and the compiler's counted vmcnt waits leave the newest gather in flight across
+//     the whole MFMA block;
+//   * ring_body2 (two tiles per wave and turn): a static loop over the ring indices, every load unconditional, one wait / one
+//     signal per offset for both tiles — the layers of the reference's blocks (5 tiles per SIMD) then need ONE turn of the ring;
+//   * spx_conv_ring_plan (cached per rule table like the grouped rows) cuts the rows into chunks (<= 4096 rows), gives every
+//     XCD the same number of chunks chosen greedily by weight (the chunk's rows stay in that XCD's L2), orders an XCD's tiles by
+//     their number of non-empty offsets and deals them round by round over its 128 SIMD bins, a row's heaviest tile to the bin
+//     that carries the least — the launch lasts as long as its fullest SIMD; it also picks the body from the LIVE row count;
 //   * optional epilogue: per-workgroup column sums of y and y*y (the statistics pass of the training-mode BatchNorm1d that
 //     follows every sparse conv, reference spconv_backbone.py:26-27,81), consumed by spx_bn_relu_fwd_from_sums.
 //
