@@ -353,78 +353,93 @@ __global__ void k_fill_neg1(int32_t* pair, int64_t ld, const int64_t* d_n_out) {
     pair[(int64_t)blockIdx.y * ld + o] = -1;
 }
 
-// Both tables of the strided conv, input-driven, one thread per (input voxel, offset): pair_bwd[k][i] = output row fed by
-// input i at offset k (coalesced along i) and the valid entries of pair_fwd[k][row] = i scattered over the -1 rows.
+// Both tables of the strided conv, input-driven: pair_bwd[k][i] = output row fed by input i at offset k (coalesced along i)
+// and the valid entries of pair_fwd[k][row] = i scattered over the -1 rows.  One thread per (input voxel, kz) walking the
+// (ky, kx) plane like k_mark (round 3; before: one thread per (voxel, offset) = 27 x the index loads and three run-time integer
+// divisions per thread to split the offset — the arithmetic the index kernels are bound by): the per-axis tests are shared, and
+// only the 3.4 of 27 candidates that land on an output cell touch the bitmap.
 __global__ void k_conv_pairs(const int32_t* __restrict__ idx, int64_t n, const int64_t* d_n, int batch, ConvGeom g,
                              const uint64_t* __restrict__ bits, const uint32_t* __restrict__ prefix,
                              int32_t* __restrict__ pair_fwd, int64_t cap, int32_t* __restrict__ pair_bwd,
                              int32_t* cnt) {
-  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  int k = blockIdx.y;
-  int32_t row = -1;
-  bool live = i < spx_live_n(d_n, n);
-  if (live) {
-    int4 c = reinterpret_cast<const int4*>(idx)[i];
-    int64_t key = in_grid(c, batch, g.in_shape) ? cand_key(c, k, g) : -1;
-    if (key >= 0) {
-      const uint64_t w = bits[key >> 6];                 // the cell is marked by construction: both loads are independent
-      const uint32_t r = prefix[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1));
-      if ((int64_t)r < cap) {
-        row = (int32_t)r;
-        pair_fwd[(int64_t)k * cap + r] = (int32_t)i;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int kz = blockIdx.y;
+  const bool live = i < spx_live_n(d_n, n);
+  int4 c = make_int4(-1, -1, -1, -1);
+  if (live) c = reinterpret_cast<const int4*>(idx)[i];
+  const int oz = (live && in_grid(c, batch, g.in_shape)) ? cand_axis(c.y, kz, g, 0) : -1;
+  for (int ky = 0; ky < g.ks.v[1]; ++ky) {
+    const int oy = oz >= 0 ? cand_axis(c.z, ky, g, 1) : -1;
+    for (int kx = 0; kx < g.ks.v[2]; ++kx) {
+      const int k = (kz * g.ks.v[1] + ky) * g.ks.v[2] + kx;
+      int32_t row = -1;
+      if (oy >= 0) {
+        const int ox = cand_axis(c.w, kx, g, 2);
+        if (ox >= 0) {
+          const int64_t key = spx_lin_key(c.x, oz, oy, ox, g.out_shape);
+          const uint64_t w = bits[key >> 6];               // the cell is marked by construction: both loads are independent
+          const uint32_t r = prefix[key >> 6] + __popcll(w & ((1ull << (key & 63)) - 1));
+          if ((int64_t)r < cap) {
+            row = (int32_t)r;
+            pair_fwd[(int64_t)k * cap + r] = (int32_t)i;
+          }
+        }
+      }
+      if (live) pair_bwd[(int64_t)k * n + i] = row;
+      if (cnt != nullptr) {
+        const unsigned long long m = __ballot(row >= 0);
+        if (spx_lane() == 0 && m) atomicAdd(&cnt[k], __popcll(m));
       }
     }
-    pair_bwd[(int64_t)k * n + i] = row;
-  }
-  if (cnt != nullptr) {
-    unsigned long long m = __ballot(row >= 0);
-    if (spx_lane() == 0 && m) atomicAdd(&cnt[k], __popcll(m));
   }
 }
 
 // Submanifold table of the OUTPUT level from the same bitmap: its rows are in rank order (= canonical key order), so the
 // neighbour at offset k of row o is rank_of(key(coord(o) + (k - centre) * dil)) — one word load + one popcount instead of
-// a hash probe, and no hash build at all.  grid (ceil(cap / 256), KZ * KY): a thread resolves the KX neighbours of one
-// (kz, ky) line, which sit in one bitmap word (two at a word boundary); rows of one offset contiguous -> coalesced stores.
+// a hash probe, and no hash build at all.  grid (ceil(cap / 256), KZ): a thread resolves the KY x KX neighbours of one kz plane;
+// the KX neighbours of a line sit in one bitmap word (two at a word boundary); rows of one offset contiguous -> coalesced stores.
 __global__ void k_subm_from_bitmap(const int32_t* __restrict__ out_idx, const int64_t* __restrict__ d_n_out, int64_t cap,
                                    Int3 shape, Int3 ks, Int3 dil, const uint64_t* __restrict__ bits,
                                    const uint32_t* __restrict__ prefix, int32_t* __restrict__ pair, int64_t ld,
                                    int32_t* cnt) {
   const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int ky = blockIdx.y % ks.v[1], kz = blockIdx.y / ks.v[1];
+  const int kz = blockIdx.y;                 // round 3: a thread walks the KY lines of its kz plane (one index load for all)
   int64_t nlive = *d_n_out;
   if (nlive > cap) nlive = cap;
   const bool live = o < nlive;
   int4 c = make_int4(0, 0, 0, 0);
   if (live) c = reinterpret_cast<const int4*>(out_idx)[o];
   const int z = c.y + (kz - ks.v[0] / 2) * dil.v[0];
-  const int y = c.z + (ky - ks.v[1] / 2) * dil.v[1];
-  const bool line_ok = live && (unsigned)z < (unsigned)shape.v[0] && (unsigned)y < (unsigned)shape.v[1];
-  const int64_t line_key = line_ok ? spx_lin_key(c.x, z, y, 0, shape) : 0;
-  int64_t w_cached = -1;
-  uint64_t w_bits = 0;
-  uint32_t w_pre = 0;
-  for (int kx = 0; kx < ks.v[2]; ++kx) {
-    const int k = (kz * ks.v[1] + ky) * ks.v[2] + kx;
-    const int x = c.w + (kx - ks.v[2] / 2) * dil.v[2];
-    int32_t r = -1;
-    if (line_ok && (unsigned)x < (unsigned)shape.v[2]) {
-      const int64_t key = line_key + x;
-      if ((key >> 6) != w_cached) {
-        w_cached = key >> 6;
-        w_bits = bits[w_cached];
-        w_pre = prefix[w_cached];
+  const bool plane_ok = live && (unsigned)z < (unsigned)shape.v[0];
+  for (int ky = 0; ky < ks.v[1]; ++ky) {
+    const int y = c.z + (ky - ks.v[1] / 2) * dil.v[1];
+    const bool line_ok = plane_ok && (unsigned)y < (unsigned)shape.v[1];
+    const int64_t line_key = line_ok ? spx_lin_key(c.x, z, y, 0, shape) : 0;
+    int64_t w_cached = -1;
+    uint64_t w_bits = 0;
+    uint32_t w_pre = 0;
+    for (int kx = 0; kx < ks.v[2]; ++kx) {
+      const int k = (kz * ks.v[1] + ky) * ks.v[2] + kx;
+      const int x = c.w + (kx - ks.v[2] / 2) * dil.v[2];
+      int32_t r = -1;
+      if (line_ok && (unsigned)x < (unsigned)shape.v[2]) {
+        const int64_t key = line_key + x;
+        if ((key >> 6) != w_cached) {
+          w_cached = key >> 6;
+          w_bits = bits[w_cached];
+          w_pre = prefix[w_cached];
+        }
+        const uint64_t bit = 1ull << (key & 63);
+        if (w_bits & bit) {
+          const uint32_t rr = w_pre + __popcll(w_bits & (bit - 1));
+          if ((int64_t)rr < cap) r = (int32_t)rr;
+        }
       }
-      const uint64_t bit = 1ull << (key & 63);
-      if (w_bits & bit) {
-        const uint32_t rr = w_pre + __popcll(w_bits & (bit - 1));
-        if ((int64_t)rr < cap) r = (int32_t)rr;
+      if (live) pair[(int64_t)k * ld + o] = r;
+      if (cnt != nullptr) {
+        const unsigned long long m = __ballot(r >= 0);
+        if (spx_lane() == 0 && m) atomicAdd(&cnt[k], __popcll(m));
       }
-    }
-    if (live) pair[(int64_t)k * ld + o] = r;
-    if (cnt != nullptr) {
-      const unsigned long long m = __ballot(r >= 0);
-      if (spx_lane() == 0 && m) atomicAdd(&cnt[k], __popcll(m));
     }
   }
 }
@@ -573,10 +588,10 @@ extern "C" int spx_conv_rulebook(const int32_t* idx, int64_t n_in, const int64_t
   unsigned nb_cap = (unsigned)((cap + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_fill_neg1, dim3(nb_cap > 256 ? 256 : nb_cap, K), dim3(kBlock), 0, s, pair_fwd, cap, d_n_out);
   if (n_in > 0)
-    hipLaunchKernelGGL(k_conv_pairs, dim3(nb_in, K), dim3(kBlock), 0, s, idx, n_in, d_n_in, batch, g, w.bits, w.prefix,
+    hipLaunchKernelGGL(k_conv_pairs, dim3(nb_in, (unsigned)ksize[0]), dim3(kBlock), 0, s, idx, n_in, d_n_in, batch, g, w.bits, w.prefix,
                        pair_fwd, cap, pair_bwd, cnt);
   if (subm_pair)
-    hipLaunchKernelGGL(k_subm_from_bitmap, dim3((unsigned)((cap + kBlock - 1) / kBlock), (unsigned)(subm_ksize[0] * subm_ksize[1])),
+    hipLaunchKernelGGL(k_subm_from_bitmap, dim3((unsigned)((cap + kBlock - 1) / kBlock), (unsigned)subm_ksize[0]),
                        dim3(kBlock), 0, s, out_idx,
                        d_n_out, cap, g.out_shape, spx_i3(subm_ksize), spx_i3(subm_dil), w.bits, w.prefix, subm_pair, cap,
                        subm_cnt);
