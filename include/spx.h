@@ -46,6 +46,9 @@ extern "C" {
                                      capacity (static-capacity mode); rows beyond it were dropped; via d_status          */
 #define SPX_ERR_TABLE_FULL (-6)   /* DEVICE-side: a hash probe sequence found no free slot (stale workspace declared
                                      pre-cleared); reported through a d_status word, see spx_read_status()  */
+#define SPX_ERR_RING_STALL (-8)   /* DEVICE-side: a wave of spx_conv_gemm_ring gave up a (bounded) wait on the weight ring:
+                                     the launch's output is incomplete; via d_status.  Never seen; the exit exists so that a
+                                     protocol fault ends as an error code and not as a hung GPU                            */
 
 /* flags of the entry points that keep a hash table in their workspace (spx_voxelize, spx_subm_rulebook) */
 #define SPX_WS_PRECLEARED 1 /* the caller has already initialised the workspace (hash keys = 0xFF bytes, values / point
@@ -245,7 +248,8 @@ int spx_conv_gemm_balanced(const float *src, int c_src, const float *w_packed, i
  * floats, row b = column sums of the written values and of their squares over the rows workgroup b wrote — the statistics
  * pass of the training-mode BatchNorm1d that follows (reference spconv_backbone.py:26-27,81), consumed by
  * spx_bn_relu_fwd_from_sums.  Every output row is the same sum over k in ascending order whatever the plan: bitwise
- * reproducible.  Channel pairs: (32|64) x (32|64); others SPX_ERR_UNSUPPORTED.  kvol <= 31. */
+ * reproducible.  Channel pairs: (32|64) x (32|64); others SPX_ERR_UNSUPPORTED.  kvol <= 31.  d_status (nullable, see
+ * spx_read_status) receives SPX_ERR_RING_STALL if a wave's bounded wait on the ring gave up. */
 /* spx_conv_ring_tiles_per_wave(set): tuning knob of spx_conv_ring_plan, process-wide.  0 (default): by size — a wave holds one
  * 16-row tile per turn of the weight ring while one turn covers all live rows, two tiles (sharing the ring protocol of every
  * offset) beyond that; 1 / 2: always that many (environment SPX_RING_TM presets it; tests and A/B runs).  Returns the
@@ -258,7 +262,7 @@ int spx_conv_ring_plan(const int32_t *pair, int64_t pair_ld, int kvol, int64_t n
 int spx_conv_gemm_ring(const float *src, int64_t n_src, int c_src, const float *w_packed, int c_dst, int kvol, int flip_k,
                        const int32_t *pair, int64_t pair_ld, int64_t n_dst, const int64_t *d_n_dst, const float *scale,
                        const float *shift, int relu, int32_t *plan, const int32_t *perm, float *dst, float *stats,
-                       spx_stream_t stream);
+                       int32_t *d_status, spx_stream_t stream);
 
 size_t spx_conv_wgrad_ws_bytes(int cin, int cout, int kvol, int64_t n_out);
 /* counts (nullable): the table's pair counts from spx_conv_wgrad_counts (device, spx_conv_wgrad_counts_bytes); they depend on

@@ -213,6 +213,7 @@ def test_ring_argument_checks():
     lib = _lib.load()
     assert lib.spx_conv_ring_plan(None, 10, 27, 10, None, None, None) == -1
     assert lib.spx_conv_gemm_ring(None, 1, 64, None, 64, 27, 0, None, 10, 10, None, None, None, 0, None, None, None, None,
-                                  None) == -1
+                                  None, None) == -1
+    assert b"ring" in lib.spx_strerror(-8)
     assert lib.spx_conv_ring_stat_rows() == 256
     assert lib.spx_conv_ring_plan_bytes(100000) > 0

@@ -10,6 +10,7 @@ extern "C" const char* spx_strerror(int code) {
     case SPX_ERR_LAUNCH: return "HIP kernel launch failed";
     case SPX_ERR_TOO_LARGE: return "problem too large (rows >= 2^31 or grid cells >= 2^40)";
     case SPX_ERR_CAPACITY: return "device: more active outputs than the static row capacity of a rule table; rows dropped";
+    case SPX_ERR_RING_STALL: return "device: a bounded wait on the weight ring of spx_conv_gemm_ring gave up; output incomplete";
     case SPX_ERR_TABLE_FULL: return "device: hash table full (workspace declared pre-cleared holds stale keys); rows dropped";
     default: return "unknown spx error code";
   }

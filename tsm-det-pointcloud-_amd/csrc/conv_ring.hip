@@ -337,11 +337,13 @@ struct RingCtl {
   int* done;
   int* abort;
   int32_t* plan;
+  int32_t* status;   // device status word (nullable): receives SPX_ERR_RING_STALL
 };
 
 __device__ __forceinline__ void ring_give_up(const RingCtl& c, int lane) {
   if (lane == 0) {
     atomicAdd(&c.plan[2], 1);
+    if (c.status) atomicMin(c.status, (int32_t)SPX_ERR_RING_STALL);
     __hip_atomic_store(c.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
@@ -420,7 +422,7 @@ __device__ __forceinline__ void ring_body1(
     const float* __restrict__ src, int64_t n_src, const float* __restrict__ wp, const int32_t* __restrict__ pair, int64_t ld,
     int K, int flip, int64_t n, const int64_t* d_n, const float* __restrict__ scale, const float* __restrict__ shift,
     int relu, int32_t* __restrict__ plan, int64_t tcap, const int32_t* __restrict__ perm, float* __restrict__ dst,
-    float* __restrict__ stats, f32x4* smem) {
+    float* __restrict__ stats, int32_t* status, f32x4* smem) {
   constexpr int NT = CD / 16;
   constexpr int JG = CS / 16;
   constexpr int NF = NT * JG;                 // 1 KiB weight fragments per offset
@@ -437,7 +439,7 @@ __device__ __forceinline__ void ring_body1(
   if (threadIdx.x < 2 * kSlots + 1) s_ready[threadIdx.x] = 0;
   __syncthreads();                            // the only workgroup barrier before the statistics epilogue
 
-  const RingCtl ctl{ring, s_ready, s_done, s_abort, plan};
+  const RingCtl ctl{ring, s_ready, s_done, s_abort, plan, status};
   // ------------------------------------------------------------ loader waves
   if (wave >= kCW) {
 #ifdef SPX_RING_NO_PROTO
@@ -783,7 +785,7 @@ __device__ __forceinline__ void ring_body2(
     const float* __restrict__ src, int64_t n_src, const float* __restrict__ wp, const int32_t* __restrict__ pair, int64_t ld,
     int K, int flip, int64_t n, const int64_t* d_n, const float* __restrict__ scale, const float* __restrict__ shift,
     int relu, int32_t* __restrict__ plan, int64_t tcap, const int32_t* __restrict__ perm, float* __restrict__ dst,
-    float* __restrict__ stats, f32x4* smem) {
+    float* __restrict__ stats, int32_t* status, f32x4* smem) {
   constexpr int NT = CD / 16;
   constexpr int JG = CS / 16;
   constexpr int NF = NT * JG;
@@ -799,7 +801,7 @@ __device__ __forceinline__ void ring_body2(
   const int R = plan[8 + x];
   if (threadIdx.x < 2 * kSlots + 1) s_ready[threadIdx.x] = 0;
   __syncthreads();
-  const RingCtl ctl{ring, s_ready, s_done, s_abort, plan};
+  const RingCtl ctl{ring, s_ready, s_done, s_abort, plan, status};
   const int G = R * K;
   if (wave >= kCW) {
     ring_fill<NF>(ctl, wp, wave - kCW, G, K, lane);
@@ -1026,20 +1028,20 @@ __global__ __launch_bounds__(64 * (kCW + kLW)) void k_conv_ring(
     const float* __restrict__ src, int64_t n_src, const float* __restrict__ wp, const int32_t* __restrict__ pair, int64_t ld,
     int K, int flip, int64_t n, const int64_t* d_n, const float* __restrict__ scale, const float* __restrict__ shift,
     int relu, int32_t* __restrict__ plan, int64_t tcap, const int32_t* __restrict__ perm, float* __restrict__ dst,
-    float* __restrict__ stats) {
+    float* __restrict__ stats, int32_t* status) {
   __shared__ f32x4 smem[ring_smem_f4<CS, CD>()];
   if (plan[4] == 2)
-    ring_body2<CS, CD>(src, n_src, wp, pair, ld, K, flip, n, d_n, scale, shift, relu, plan, tcap, perm, dst, stats, smem);
+    ring_body2<CS, CD>(src, n_src, wp, pair, ld, K, flip, n, d_n, scale, shift, relu, plan, tcap, perm, dst, stats, status, smem);
   else
-    ring_body1<CS, CD>(src, n_src, wp, pair, ld, K, flip, n, d_n, scale, shift, relu, plan, tcap, perm, dst, stats, smem);
+    ring_body1<CS, CD>(src, n_src, wp, pair, ld, K, flip, n, d_n, scale, shift, relu, plan, tcap, perm, dst, stats, status, smem);
 }
 
 template <int CS, int CD>
 static void launch_ring(const float* src, int64_t n_src, const float* wp, const int32_t* pair, int64_t ld, int K, int flip,
                         int64_t n, const int64_t* d_n, const float* scale, const float* shift, int relu, int32_t* plan,
-                        const int32_t* perm, float* dst, float* stats, hipStream_t s) {
+                        const int32_t* perm, float* dst, float* stats, int32_t* status, hipStream_t s) {
   hipLaunchKernelGGL((k_conv_ring<CS, CD>), dim3(kRG), dim3(64 * (kCW + kLW)), 0, s, src, n_src, wp, pair, ld, K, flip, n, d_n,
-                     scale, shift, relu, plan, ring_tcap(n), perm, dst, stats);
+                     scale, shift, relu, plan, ring_tcap(n), perm, dst, stats, status);
 }
 
 // tiles per wave and turn of the ring of the plans this library deals: 0 = by size (two as soon as one tile per wave would
@@ -1082,7 +1084,7 @@ extern "C" int spx_conv_ring_plan(const int32_t* pair, int64_t pair_ld, int kvol
 #define SPX_RING_CASE(A, B)                                                                                          \
   if (c_src == A && c_dst == B) {                                                                                    \
     launch_ring<A, B>(src, n_src, w_packed, pair, pair_ld, kvol, flip_k, n_dst, d_n_dst, scale, shift, relu, plan, perm, \
-                      dst, stats, s);                                                                                \
+                      dst, stats, d_status, s);                                                                      \
     SPX_CHECK_LAUNCH();                                                                                              \
     return SPX_OK;                                                                                                   \
   }
@@ -1090,7 +1092,7 @@ extern "C" int spx_conv_ring_plan(const int32_t* pair, int64_t pair_ld, int kvol
 extern "C" int spx_conv_gemm_ring(const float* src, int64_t n_src, int c_src, const float* w_packed, int c_dst, int kvol,
                                   int flip_k, const int32_t* pair, int64_t pair_ld, int64_t n_dst, const int64_t* d_n_dst,
                                   const float* scale, const float* shift, int relu, int32_t* plan, const int32_t* perm,
-                                  float* dst, float* stats, spx_stream_t stream) {
+                                  float* dst, float* stats, int32_t* d_status, spx_stream_t stream) {
   if (!src || !w_packed || !pair || !dst || !plan || c_src <= 0 || c_dst <= 0 || kvol <= 0 || kvol > 31 || n_dst <= 0 ||
       n_src <= 0 || pair_ld < n_dst)
     return SPX_ERR_INVALID_ARG;

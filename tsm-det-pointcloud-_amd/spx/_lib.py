@@ -59,7 +59,7 @@ SIGNATURES = {
     "spx_conv_ring_tiles_per_wave": (_int, [_int]),
     "spx_conv_ring_plan": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp]),
     "spx_conv_gemm_ring": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp,
-                                  _vp, _vp]),
+                                  _vp, _vp, _vp]),
     "spx_conv_wgrad_ws_bytes": (_sz, [_int, _int, _int, _i64]),
     "spx_conv_wgrad_counts_bytes": (_sz, [_int, _i64]),
     "spx_conv_wgrad_counts": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp]),

@@ -510,7 +510,8 @@ def conv_gemm_ring(src, w_packed, c_dst, kvol, pair, ld, n_dst, plan, flip_k=Fal
         stats = torch.empty((lib.spx_conv_ring_stat_rows(), 2, c_dst), dtype=torch.float32, device=src.device)
     check(lib.spx_conv_gemm_ring(_ptr(src), src.shape[0], src.shape[1], _ptr(w_packed), c_dst, kvol, int(bool(flip_k)),
                                  _ptr(pair), ld, n_dst, _ptr(d_n_dst), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(plan),
-                                 _ptr(perm), _ptr(dst), _ptr(stats), _stream(src)), "spx_conv_gemm_ring")
+                                 _ptr(perm), _ptr(dst), _ptr(stats), _ptr(status_word(src.device)), _stream(src)),
+          "spx_conv_gemm_ring")
     return (dst, stats) if want_stats else dst
 
 
