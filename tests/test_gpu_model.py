@@ -473,8 +473,9 @@ def test_graphed_static_capacity_forward_matches_dynamic():
 
 def test_folded_batchnorm_cache_follows_parameter_writes():
     """Inference folds BatchNorm into the conv epilogues once per module (spx.functional.folded_bn) instead of five
-    elementwise launches per layer and forward; the cache must follow every write to a parameter or running statistic —
-    in eager mode (version counters) and under a captured hipGraph (the fold is rebuilt in place before the replay)."""
+    elementwise launches per layer and forward, and a captured inference graph reads the packed weights / Winograd images of
+    the warm-up passes instead of rebuilding them in every replay; both must follow every write to a parameter or running
+    statistic — in eager mode (version counters) and under a captured hipGraph (rebuilt in place before the replay)."""
     from pcdet_amd.models.inference import GraphedDetector
     from spx import functional as F_
     _cfg, ds, model = _build(seed=12)
@@ -498,7 +499,11 @@ def test_folded_batchnorm_cache_follows_parameter_writes():
     assert torch.equal(runner(pts)["spatial_features"], first[0])
     bns = [m for m in model.modules() if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))]
     g = torch.Generator().manual_seed(3)
+    assert len(F_._GRAPH_CONSTANTS) >= 20            # packed sparse weights and Winograd images the graph reads from outside
     with torch.no_grad():
+        for m in model.modules():                    # conv weights too: the graph's packed copies / Winograd images must follow
+            if isinstance(m, torch.nn.Conv2d) or hasattr(m, "indice_key"):
+                m.weight.mul_(1.0 + 0.2 * torch.rand(m.weight.shape, generator=g).to(dev))
         for m in bns:                                # what an optimizer step / load_state_dict does: in-place writes
             m.weight.mul_((torch.rand(m.num_features, generator=g) + 0.5).to(dev))
             m.running_mean.add_((0.1 * torch.randn(m.num_features, generator=g)).to(dev))

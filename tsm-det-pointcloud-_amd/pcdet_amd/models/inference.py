@@ -14,7 +14,7 @@ it when convenient).
 """
 import torch
 
-from spx.functional import refresh_folded_bn
+from spx.functional import refresh_folded_bn, refresh_graph_constants
 
 DEFAULT_LEVEL_FACTORS = {'spconv2': 2.0, 'spconv3': 2.0, 'spconv4': 1.0, 'spconv_down2': 1.0}
 
@@ -93,6 +93,7 @@ class GraphedDetector(object):
         if n < self.max_points:
             self.points[n:] = self._pad_row
         refresh_folded_bn(self.model)        # BatchNorm folds the graph captured: rebuilt in place if a parameter was written
+        refresh_graph_constants()            # likewise the packed weights / Winograd images it reads
         self.graph.replay()
         return self.out
 

@@ -20,7 +20,13 @@ def _packed(weight, mode):
     always off.  While a hipGraph is being captured the pack kernel is always recorded, so a replay never reads a stale
     copy."""
     if weight.is_cuda and torch.cuda.is_current_stream_capturing():
-        return ops.pack_weight(weight, mode)
+        if not torch.is_grad_enabled():           # an inference graph: the copy the warm-up passes cached, kept current by
+            holder = weight._base if weight._base is not None else weight          # refresh_graph_constants()
+            hit = (getattr(holder, "_spx_packed", None) or {}).get(
+                (mode, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride())))
+            if hit is not None and hit[0] == weight._version:
+                return _graph_constant(weight, hit[1], lambda w, out, mode=mode: ops.pack_weight(w, mode, out=out))
+        return ops.pack_weight(weight, mode)      # a graph that trains (or no cached copy): the graph owns its buffers
     holder = weight._base if weight._base is not None else weight
     cache = getattr(holder, "_spx_packed", None)
     if cache is None:
@@ -80,6 +86,36 @@ def folded_bn(bn, conv_bias=None):
             scale, shift, inv = scale.contiguous(), shift.contiguous(), inv.contiguous()
     _FOLDED[bn] = (key, scale, shift, inv, weakref.ref(conv_bias) if conv_bias is not None else None)
     return scale, shift, inv
+
+
+_GRAPH_CONSTANTS = []      # [weakref(weight), version, buffer, refill(out)] of the constants inference graphs captured
+
+
+def _graph_constant(weight, buf, refill):
+    """Inference graphs only (capture in progress, no gradient recorded): let the graph read `buf` — the re-laid copy of `weight`
+    (packed MFMA operand, Winograd image) that the eager warm-up passes before the capture left in the per-weight cache — instead
+    of recording the kernel that rebuilds it: 13 pack + 10 transform launches of 3-9 us sat on the critical path of every
+    captured forward (rocprofv3 timeline of a replay, round 3).  The buffer is registered; refresh_graph_constants() refills it
+    IN PLACE when the weight was written since (GraphedDetector.__call__ runs it before every replay)."""
+    holder = weight._base if weight._base is not None else weight      # a per-call view (BEV entry conv) dies with the call
+    geom = (tuple(weight.shape), tuple(weight.stride()), weight.storage_offset())
+    _GRAPH_CONSTANTS.append([weakref.ref(holder), weight._version, buf, refill, geom])
+    return buf
+
+
+def refresh_graph_constants():
+    """Refill, in place, every constant an inference graph captured whose weight was written since (host-side version checks
+    only while nothing changed); entries of weights that no longer exist are dropped."""
+    keep = []
+    for ent in _GRAPH_CONSTANTS:
+        w = ent[0]()
+        if w is None:
+            continue
+        if ent[1] != w._version:
+            ent[3](w.detach().as_strided(*ent[4]), ent[2])
+            ent[1] = w._version
+        keep.append(ent)
+    _GRAPH_CONSTANTS[:] = keep
 
 
 def refresh_folded_bn(model):
@@ -501,7 +537,12 @@ def _wino_image(weight, flip):
     # no spx_wino_weight was recorded, and every replay after the first optimizer.step() convolved with the weights of capture
     # time while dgrad / wgrad used the current ones.)
     if weight.is_cuda and torch.cuda.is_current_stream_capturing():
-        return ops.wino_weight(weight, flip)            # a captured graph owns its buffers
+        hit = getattr(weight, '_spx_wino_flip' if flip else '_spx_wino', None)
+        if (not torch.is_grad_enabled() and hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr()
+                and hit[2].device == weight.device):
+            # an inference graph reads the image the warm-up passes cached; refresh_graph_constants() keeps it current
+            return _graph_constant(weight, hit[2], lambda w, out, flip=flip: ops.wino_weight(w, flip, out=out))
+        return ops.wino_weight(weight, flip)            # a graph that trains owns its buffers
     attr = '_spx_wino_flip' if flip else '_spx_wino'
     hit = getattr(weight, attr, None)
     fresh = hit is not None and hit[1] == weight.data_ptr() and hit[2].device == weight.device

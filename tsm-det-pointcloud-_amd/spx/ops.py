@@ -308,14 +308,17 @@ class PendingRulebook(object):
 
 # ------------------------------------------------------------------------------------------- arithmetic
 
-def pack_weight(weight, mode):
-    """weight [Cout, kz, ky, kx, Cin] (or [Cout, K, Cin]) -> MFMA operand order.  mode 0 fwd, 1 dgrad, 2 both."""
+def pack_weight(weight, mode, out=None):
+    """weight [Cout, kz, ky, kx, Cin] (or [Cout, K, Cin]) -> MFMA operand order.  mode 0 fwd, 1 dgrad, 2 both.  out: a buffer
+    of a previous call with the same weight shape and mode, refilled in place."""
     _need_gpu(weight)
     lib = _lib.load()
     w = weight.detach().contiguous().float()
     cout, cin = w.shape[0], w.shape[-1]
     K = w.numel() // (cout * cin)
-    packed = torch.empty(((2 if mode == 2 else 1) * K * cin * cout,), dtype=torch.float32, device=w.device)
+    n = (2 if mode == 2 else 1) * K * cin * cout
+    packed = out if out is not None else torch.empty((n,), dtype=torch.float32, device=w.device)
+    assert packed.numel() == n and packed.is_contiguous() and packed.device == w.device
     check(lib.spx_pack_weight(_ptr(w), cout, K, cin, mode, _ptr(packed), _stream(w)), "spx_pack_weight")
     return packed                # mode 2: forward operand in the first half, dgrad operand in the second
 

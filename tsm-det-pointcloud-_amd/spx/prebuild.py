@@ -12,6 +12,8 @@ Replaces the lazy, in-line indice-pair builds of spconv.pytorch's modules (refer
 pcdet/models/backbones_3d/spconv_backbone.py:86-122); the tables are the same objects the modules would have built
 themselves (`indice_dict[indice_key]`), so module code and results do not change.
 """
+import os
+
 import torch
 
 from . import ops
@@ -63,7 +65,21 @@ def prebuild(x, convs, backward=None):
     users = {}
     for m in convs:
         users.setdefault(m.indice_key, []).append(m)
-    side.wait_stream(main)
+    if torch.cuda.is_current_stream_capturing():
+        # hipGraph replay (ROCm 7) cuts a captured graph into chains by a depth-first walk that follows, at every node, the child
+        # captured FIRST; each chain runs on a stream of its own and those streams share a hardware queue, in which a chain whose
+        # head waits for a late index kernel blocks every chain submitted behind it.  With the plain fork below the walk follows
+        # the index chain, chops the compute chain at every table event, and the first convolution of the replay sat behind a
+        # barrier until the LAST plan it shared a queue with was built (rocprofv3: conv_input at 430 us instead of ~110).  Fork from
+        # an event instead and capture one compute-stream node before the index stream's first: the walk then takes the compute
+        # chain in one piece and the index chain becomes the single side chain.
+        fork = torch.cuda.Event()
+        fork.record(main)
+        ops.status_word(dev).add_(0)
+        side.wait_event(fork)
+    else:
+        fork = None
+        side.wait_stream(main)
     built = 0
     caps = x.static_caps or {}
     with torch.cuda.stream(side):
