@@ -12,6 +12,8 @@ to `level_factors` x the voxel capacity (LiDAR scenes shrink after the first str
 per stage).  Rows beyond a capacity are dropped and reported by `overflowed()` (reads the device counters: one sync, call
 it when convenient).
 """
+import os
+
 import torch
 
 from spx.functional import refresh_folded_bn, refresh_graph_constants
@@ -66,8 +68,13 @@ class GraphedDetector(object):
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
+        dot = os.environ.get("SPX_GRAPH_DOT")           # dev knob: write the captured graph (nodes + dependencies) as DOT
+        if dot:
+            self.graph.enable_debug_mode()
         with torch.cuda.graph(self.graph):
             self.out = self._forward()
+        if dot:
+            self.graph.debug_dump(dot)
 
     def _forward(self):
         bd = {'points': self.points, 'batch_size': self.batch_size, 'static_caps': self.static_caps}
