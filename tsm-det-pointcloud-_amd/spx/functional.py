@@ -99,6 +99,9 @@ def _graph_constant(weight, buf, refill):
     IN PLACE when the weight was written since (GraphedDetector.__call__ runs it before every replay)."""
     holder = weight._base if weight._base is not None else weight      # a per-call view (BEV entry conv) dies with the call
     geom = (tuple(weight.shape), tuple(weight.stride()), weight.storage_offset())
+    for ent in _GRAPH_CONSTANTS:           # a second graph over the same model reads the same buffers: one entry per buffer
+        if ent[2].data_ptr() == buf.data_ptr() and ent[0]() is holder:
+            return buf
     _GRAPH_CONSTANTS.append([weakref.ref(holder), weight._version, buf, refill, geom])
     return buf
 
