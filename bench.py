@@ -584,7 +584,7 @@ def rulebook_rates(points, geom, batch, max_voxels, iters=30):
     for j, (k, s, p) in enumerate(strided):
         n = idx.shape[0]
         if j == 0:     # level 1 rows arrive in voxeliser order: the one hash-built table of a forward pass
-            out["subm_hash"].append((n, ev_time(lambda: ops.subm_rulebook(idx, batch, shape, (3, 3, 3)))))
+            out["subm_hash"].append((n, ev_time(lambda: ops.subm_rulebook(idx, batch, shape, (3, 3, 3), unique=True))))   # as the modules call it
         rb = ops.conv_rulebook(idx, batch, shape, k, s, p)
         out["strided"].append((n, ev_time(lambda: ops.conv_rulebook(idx, batch, shape, k, s, p, sync=False))))
         if j < 3:      # strided tables + the submanifold table of the output level from the same rank bitmap, one call

@@ -56,6 +56,11 @@ extern "C" {
                                clearing launches.  A workspace that is NOT clean makes the kernels drop the rows they cannot
                                place and raise SPX_ERR_TABLE_FULL in d_status; every probe loop is bounded by the slot count */
 
+#define SPX_ROWS_UNIQUE 2   /* spx_subm_rulebook: the caller guarantees one row per cell (a voxeliser's output; what spconv
+                               requires of SparseConvTensor.indices).  The table is then symmetric and only half of it is probed,
+                               every hit written twice.  With duplicate rows under this flag the result is undefined (without
+                               it duplicates resolve to the smallest row)                                                  */
+
 #define SPX_MAX_KVOL 32 /* largest kernel volume kz*ky*kx supported (27 = 3x3x3 is the reference's max) */
 
 typedef void *spx_stream_t;

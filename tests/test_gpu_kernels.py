@@ -168,6 +168,38 @@ def test_rulebooks_bit_exact_vs_oracle(cfg_id, nframes, orc):
             idx_np, shape = oi, oshape  # feed the next level
 
 
+@pytest.mark.parametrize("cfg_id,nframes", [(1, 2), (2, 4), (5, 1)])
+def test_subm_rulebook_symmetric_probe_equals_full_probe(cfg_id, nframes, orc):
+    """SPX_ROWS_UNIQUE (what the modules pass: spconv's one-row-per-cell contract): half of the table probed, every hit written
+    twice — bit-identical to the full probe (which the test above pins to the oracle), for the reference's 3x3x3 tables in
+    voxeliser order and canonical order, other odd kernels, a dilation, a device-side live count, rows outside the grid, and
+    a 1x1x1 / an even kernel (which take the full probe)."""
+    from spx import ops
+    idx_np, shape = _frame_indices(orc, cfg_id, nframes)
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    canon = torch.from_numpy(idx_np).to(dev)
+    shuffled = canon[torch.randperm(canon.shape[0], generator=g).to(dev)]
+    for d_idx in (canon, shuffled):
+        for k, dil in (((3, 3, 3), (1, 1, 1)), ((3, 1, 1), (1, 1, 1)), ((1, 3, 5), (1, 1, 1)), ((3, 3, 3), (1, 2, 2)),
+                       ((1, 1, 1), (1, 1, 1)), ((2, 2, 2), (1, 1, 1))):
+            full = ops.subm_rulebook(d_idx, nframes, shape, k, dil)
+            sym = ops.subm_rulebook(d_idx, nframes, shape, k, dil, unique=True)
+            assert torch.equal(sym.pair, full.pair), (k, dil)
+    n = canon.shape[0]
+    d_n = torch.tensor([n - 777], dtype=torch.int64, device=dev)
+    full = ops.subm_rulebook(shuffled, nframes, shape, (3, 3, 3), d_n=d_n)
+    sym = ops.subm_rulebook(shuffled, nframes, shape, (3, 3, 3), d_n=d_n, unique=True)
+    assert torch.equal(sym.pair[:, :n - 777], full.pair[:, :n - 777])
+    outside = shuffled.clone()
+    outside[5::97, 1] = shape[0] + 3                      # rows outside the grid: in no cell, neighbours of nobody
+    outside[11::89, 3] = -2
+    full = ops.subm_rulebook(outside, nframes, shape, (3, 3, 3))
+    sym = ops.subm_rulebook(outside, nframes, shape, (3, 3, 3), unique=True)
+    assert torch.equal(sym.pair, full.pair)
+    ops.check_status(dev)
+
+
 def test_rulebook_edge_cases(orc):
     from spx import ops
     dev = _dev()

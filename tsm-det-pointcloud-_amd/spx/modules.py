@@ -248,8 +248,9 @@ class SparseConvolution(SparseModule):
                 raise ValueError("indice_key %r was built for a different tensor / kernel" % self.indice_key)
             return cached
         if self.subm:
+            # unique: spconv's contract for SparseConvTensor.indices (one row per active cell)
             rb = ops.subm_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation,
-                                   d_n=x.n_valid)
+                                   d_n=x.n_valid, unique=True)
         elif x.n_valid is not None:     # static-capacity mode: no host sync, rows at capacity
             cap = (x.static_caps or {}).get(self.indice_key, None)
             rb = ops.conv_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,

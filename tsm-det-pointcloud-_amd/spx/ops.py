@@ -196,9 +196,10 @@ def mean_vfe(voxels, num_points):
 # ------------------------------------------------------------------------------------------- rulebooks
 
 def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None,
-                  ws_precleared=False):
+                  ws_precleared=False, unique=False):
     """d_n: optional device int64[1] live row count (<= indices.shape[0], which is then the capacity).  Device-side
-    errors (only possible with ws_precleared on a dirty workspace) go to the sticky status word: check_status()."""
+    errors (only possible with ws_precleared on a dirty workspace) go to the sticky status word: check_status().
+    unique: the caller guarantees one row per cell (SPX_ROWS_UNIQUE: half the table is probed, hits written twice)."""
     _need_gpu(indices)
     lib = _lib.load()
     indices = indices.contiguous()
@@ -212,7 +213,8 @@ def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1),
     wsb = lib.spx_subm_rulebook_ws_bytes(n)
     ws = workspace(dev, wsb)
     check(lib.spx_subm_rulebook(_ptr(indices), n, _ptr(d_n), batch_size, i3(spatial_shape), i3(ksize), i3(dilation),
-                                _ptr(pair), ld, _ptr(cnt), 1 if ws_precleared else 0, _ptr(status_word(dev)), _ptr(ws), wsb,
+                                _ptr(pair), ld, _ptr(cnt), (1 if ws_precleared else 0) | (2 if unique else 0), _ptr(status_word(dev)),
+                                _ptr(ws), wsb,
                                 _stream(indices)), "spx_subm_rulebook")
     rb = Rulebook(pair, ld, n, n, K, True, indices, spatial_shape, spatial_shape, cnt=cnt, ksize=list(ksize),
                   stride=[1, 1, 1], padding=[k // 2 for k in ksize], dilation=list(dilation))

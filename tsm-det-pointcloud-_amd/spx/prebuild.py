@@ -94,7 +94,7 @@ def prebuild(x, convs, backward=None):
                 if m.subm:
                     rb = pending.pop(key, None)
                     if rb is None:
-                        rb = ops.subm_rulebook(idx, x.batch_size, shape, m.kernel_size, m.dilation, d_n=d_n)
+                        rb = ops.subm_rulebook(idx, x.batch_size, shape, m.kernel_size, m.dilation, d_n=d_n, unique=True)
                 else:
                     # the first not-yet-built submanifold conv after this one works on this conv's output level
                     nxt = next((c for c in convs[pos + 1:] if not c.inverse and c.indice_key is not None
