@@ -80,6 +80,9 @@ def wrap_ddp(model, process_group=None, late_reduce=True, **ddp_kwargs):
     """DistributedDataParallel(model, **ddp_kwargs) with the convolution weights reduced at the end of the backward pass (see the
     module docstring).  late_reduce=False: plain DDP."""
     params = late_reduced_parameters(model) if late_reduce else {}
+    late_ids = {id(p) for p in params.values()}
+    if not any(p.requires_grad and id(p) not in late_ids for p in model.parameters()):
+        params = {}        # nothing would be left for DDP itself (its communication hook arms the late reduction): plain DDP
     if params:
         DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, list(params))
         with torch.no_grad():                          # DDP does not broadcast what it ignores: rank 0's values everywhere
