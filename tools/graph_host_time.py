@@ -1,3 +1,4 @@
+"""Dev tool (GPU box): host time of one replay of the inference graph against its GPU time (profiles/r03_conv_experiments.md)."""
 import os, sys, time
 ROOT=os.environ.get("GRAFT_REPO_ROOT","/root/repo")
 for p in (ROOT, os.path.join(ROOT, "tsm-det-pointcloud-_amd")):
@@ -12,8 +13,8 @@ model.eval()
 batches = bench.make_batches(ds, 2, 4, 0, dev)
 from pcdet_amd.models.inference import GraphedDetector
 pts=batches[0]["points"]
-for pipelined in (False, True):
-    r = GraphedDetector(model, 4, int(pts.shape[0]*1.05)+64, pipelined=pipelined)
+for pipelined in (False,):        # (the per-stage capture measured in round 3 was removed again)
+    r = GraphedDetector(model, 4, int(pts.shape[0]*1.05)+64)
     for _ in range(5): r(pts)
     torch.cuda.synchronize()
     hs=[]; ts=[]
