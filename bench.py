@@ -273,11 +273,11 @@ class KernelTimer(object):
             return t._timed("conv_wgrad[mfma %dx%d]" % (cin, cout), flops, nbytes, sv["conv_wgrad"], feat_in, dout, pair, ld,
                             n_out, wshape, d_n_out, counts)
 
-        def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None):
+        def subm_rulebook(indices, batch_size, spatial_shape, ksize, dilation=(1, 1, 1), want_cnt=False, d_n=None, **kw):
             n = indices.shape[0]
             K = int(np.prod(ksize))
             return t._timed("subm_rulebook", 0.0, lambda: t._live(d_n, n) * (16.0 + K * 4.0), sv["subm_rulebook"], indices,
-                            batch_size, spatial_shape, ksize, dilation, want_cnt, d_n)
+                            batch_size, spatial_shape, ksize, dilation, want_cnt, d_n, **kw)
 
         def conv_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1),
                           want_cnt=False, **kw):
@@ -322,8 +322,8 @@ class KernelTimer(object):
             return t._timed("densify_bwd", 0.0, lambda: 8.0 * t._live(d_n, n) * c, sv["densify_bwd"], ddense, indices, batch_size,
                             spatial_shape, channels_last, d_n)
 
-        def pack_weight(weight, mode):
-            return t._timed("pack_weight", 0.0, 8.0 * weight.numel(), sv["pack_weight"], weight, mode)
+        def pack_weight(weight, mode, **kw):
+            return t._timed("pack_weight", 0.0, 8.0 * weight.numel(), sv["pack_weight"], weight, mode, **kw)
 
         def conv2d_wino(x, u, cout, scale=None, shift=None, relu=False, out=None, stats=False):
             # dense 3x3 conv of the BEV backbone, Winograd F(2x2, 3x3): the kernel EXECUTES 16 multiply-adds per 2x2 output tile
