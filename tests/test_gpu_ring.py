@@ -217,3 +217,28 @@ def test_ring_argument_checks():
     assert b"ring" in lib.spx_strerror(-8)
     assert lib.spx_conv_ring_stat_rows() == 256
     assert lib.spx_conv_ring_plan_bytes(100000) > 0
+
+
+@pytest.mark.parametrize("ksize", [(1, 3, 3), (3, 1, 1), (1, 1, 3), (3, 3, 1), (1, 5, 5)])
+def test_ring_other_kernel_volumes(ksize):
+    """Kernel volumes other than the reference's 27 (3 ... 25 offsets: the offset iterator, the flipped walk of the data
+    gradient and the plan's masks all depend on K), submanifold tables, bit-identical to spx_conv_gemm in both directions."""
+    from spx import ops
+    dev = _dev()
+    K = ksize[0] * ksize[1] * ksize[2]
+    g = torch.Generator().manual_seed(500 + K)
+    n, side = 30000, 48
+    lin = torch.randperm(side ** 3, generator=g)[:n].sort()[0]
+    idx = torch.stack([torch.zeros_like(lin), lin // (side * side), (lin // side) % side, lin % side], 1).int().to(dev)
+    rb = ops.subm_rulebook(idx, 1, [side, side, side], ksize)
+    w = (torch.randn(64, *ksize, 64, generator=g) / np.sqrt(K * 64)).to(dev)
+    wp = ops.pack_weight(w, 0)
+    x = torch.randn(n, 64, generator=g).to(dev)
+    plan = ops.conv_ring_plan(rb.pair, rb.ld, K, n)
+    _check_plan(ops, plan, rb.pair, rb.ld, K, n, n)
+    for flip in (False, True):
+        ref = ops.conv_gemm(x, wp, 64, K, rb.pair, rb.ld, n, flip_k=flip)
+        out = ops.conv_gemm_ring(x, wp, 64, K, rb.pair, rb.ld, n, plan, flip_k=flip)
+        assert torch.equal(out, ref), (ksize, flip)
+    assert _plan_header(plan)["timeouts"] == 0
+    ops.check_status(dev)
