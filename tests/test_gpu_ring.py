@@ -242,3 +242,29 @@ def test_ring_other_kernel_volumes(ksize):
         assert torch.equal(out, ref), (ksize, flip)
     assert _plan_header(plan)["timeouts"] == 0
     ops.check_status(dev)
+
+
+@pytest.mark.parametrize("ksize,n", [((3, 1, 1), 250000), ((1, 3, 3), 250000), ((1, 1, 1), 60000)])
+def test_ring_wraps_with_few_offsets(ksize, n):
+    """Fewer offsets than ring slots and several turns (the ring index runs over turn * K + k: a slot is revisited within one
+    turn's worth of offsets), and the degenerate single-offset table; all three tiles-per-wave settings (fixture)."""
+    from spx import ops
+    dev = _dev()
+    K = ksize[0] * ksize[1] * ksize[2]
+    g = torch.Generator().manual_seed(900 + K)
+    side = 96
+    lin = torch.randperm(side ** 3, generator=g)[:n].sort()[0]
+    idx = torch.stack([torch.zeros_like(lin), lin // (side * side), (lin // side) % side, lin % side], 1).int().to(dev)
+    rb = ops.subm_rulebook(idx, 1, [side, side, side], ksize)
+    w = (torch.randn(64, *ksize, 64, generator=g) / np.sqrt(K * 64)).to(dev)
+    wp = ops.pack_weight(w, 0)
+    x = torch.randn(n, 64, generator=g).to(dev)
+    plan = ops.conv_ring_plan(rb.pair, rb.ld, K, n)
+    hdr = _check_plan(ops, plan, rb.pair, rb.ld, K, n, n)
+    assert max(hdr["rounds"]) >= (2 if n > 100000 else 1)
+    for flip in (False, True):
+        ref = ops.conv_gemm(x, wp, 64, K, rb.pair, rb.ld, n, flip_k=flip)
+        out = ops.conv_gemm_ring(x, wp, 64, K, rb.pair, rb.ld, n, plan, flip_k=flip)
+        assert torch.equal(out, ref), (ksize, flip)
+    assert _plan_header(plan)["timeouts"] == 0
+    ops.check_status(dev)
